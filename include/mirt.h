@@ -1,0 +1,192 @@
+/*
+ * mirt.h -- C ABI of the MI355X (gfx950) wavefront path tracer that replaces the render loop of
+ * ByeDream/RayTracingInAWeekend's HomemadeRayTracer.
+ *
+ * The reference has no FFI: its seam is the C++ class HomemadeRayTracer
+ * (RayTracer/RayTracer/HomemadeRayTracer.h:11-33).  This header is what a replacement shared
+ * library exports and what the drop-in C++ host layer (raytracinginaweekend_amd/host/) calls.
+ * Plain pointers and sizes only; no exceptions cross the boundary; every entry point returns
+ * MIRT_OK (0) or a negative status and records a message retrievable with mirt_last_error().
+ * File:line citations below are relative to /root/reference/RayTracer/RayTracer/.
+ *
+ * A context is bound to one GPU and is single-owner (not thread-safe), like the reference's
+ * tracer that runs synchronously on the UI thread (RayTracer.cpp:251-254).
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_OK             0
+#define MIRT_ERR_ARG       -1   /* bad argument / inconsistent scene                    */
+#define MIRT_ERR_HIP       -2   /* a HIP runtime call failed (message has the detail)   */
+#define MIRT_ERR_STATE     -3   /* call order violated (e.g. render before upload)      */
+#define MIRT_ERR_NOMEM     -4
+
+enum { MIRT_PRIM_SPHERE = 0, MIRT_PRIM_RECT = 1 };
+/* Materials.h:7-15 (MaterialID) */
+enum { MIRT_MAT_DIFFUSE_LIGHT = 0, MIRT_MAT_LAMBERTIAN = 1, MIRT_MAT_METAL = 2, MIRT_MAT_DIELECTRIC = 3 };
+#define MIRT_CHILD_NONE ((int32_t)0x80000000)
+/* prim_axes (rect): aAxis | bAxis<<2 | cAxis<<4 | reverseFace<<6 | hasRotationChain<<7 */
+#define MIRT_AXES_PACK(a, b, c, rev, rot) ((uint32_t)((a) | ((b) << 2) | ((c) << 4) | ((rev) << 6) | ((rot) << 7)))
+
+/*
+ * Flattened scene: what World::ConstructWorld (World.cpp:15-110) leaves behind, as SoA arrays.
+ *  - a primitive is one leaf hitable together with its instance chain:
+ *      sphere = TranslatedInstance(SphereHitable(0,r))                        SimpleObject.cpp:136
+ *      rect   = TranslatedInstance(RotZ(RotY(RotX(AxisAlignedRectHitable))))  SimpleObject.cpp:173-181
+ *  - an object is one `Object` (SimpleObject.h:27-49): a run of primitives; SimpleObjectCube's
+ *    HitableCombo (SimpleObject.cpp:261-276) is an object of six rect primitives
+ *  - the BVH is the SimpleObjectBVHNode tree (SimpleObject.cpp:293-346), children >= 0 are nodes,
+ *    children < 0 are objects (~child), MIRT_CHILD_NONE is a null child (SimpleObject.cpp:311)
+ * All host pointers are borrowed for the duration of the call.
+ */
+typedef struct mirt_scene {
+    uint32_t        n_prims;
+    const uint32_t *prim_kind;   /* MIRT_PRIM_*                                            */
+    const float    *prim_off;    /* [3n] TranslatedInstance::m_offset, Hitables.h:87       */
+    const float    *prim_geom;   /* [5n] sphere: radius ; rect: a0,a1,b0,b1,c Hitables.h:50 */
+    const uint32_t *prim_axes;   /* rect: MIRT_AXES_PACK                                   */
+    const float    *prim_rot;    /* [6n] sin,cos of the x,y,z RotatedInstance, Hitables.h:97-98 */
+    const uint32_t *prim_mat;    /* material index                                         */
+    uint32_t        n_objects;
+    const uint32_t *obj_first;
+    const uint32_t *obj_count;
+    uint32_t        n_mats;
+    const uint32_t *mat_kind;    /* MIRT_MAT_*                                             */
+    const float    *mat_albedo;  /* [3n] ITexture2D::Sample of a single-colour texture     */
+    const float    *mat_fuzz;    /* [n]  Metal::m_data.fuzziness.x   Materials.cpp:96      */
+    const float    *mat_ior;     /* [n]  Dielectric refractiveIndex  Materials.cpp:169     */
+    const float    *mat_emit;    /* [3n] DiffuseLight intensity      Materials.cpp:257     */
+    uint32_t        n_nodes;     /* may be 0: the library then builds its own BVH          */
+    const float    *node_min;    /* [3n] SimpleObjectBVHNode::m_bindingBox                 */
+    const float    *node_max;    /* [3n]                                                   */
+    const int32_t  *node_left;
+    const int32_t  *node_right;
+    int32_t         root;
+    float           ambient[3];  /* LightSources::GetAmbientLight, LightSources.h:21       */
+} mirt_scene;
+
+/* The SimpleCamera members GetRay reads (SimpleCamera.h:35-56, SimpleCamera.cpp:55-60). */
+typedef struct mirt_camera {
+    float origin[3], top_left[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius;
+} mirt_camera;
+
+/* HitRecord, Hitables.h:9-17 (material pointer -> index; prim = winning primitive) */
+typedef struct mirt_hit {
+    float   t, pos[3], nrm[3], u, v;
+    int32_t mat;
+    int32_t prim;
+} mirt_hit;
+
+/* render flags */
+#define MIRT_FLAG_ONE_SPP        1u  /* m_enable1SPP,          HomemadeRayTracer.cpp:114-121 */
+#define MIRT_FLAG_NORMAL_DISPLAY 2u  /* m_enableNormalDisplay, HomemadeRayTracer.cpp:164-167 */
+#define MIRT_FLAG_ACCEL_LIST     4u  /* closest hit by a linear pass over all objects instead
+                                        of the BVH (what HitableCombo::Hit does, Hitables.cpp:130-142) */
+#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for tiny scenes, BVH otherwise     */
+
+typedef struct mirt_render_params {
+    uint32_t width, height;      /* image->m_width/m_height, HomemadeRayTracer.cpp:100-101 */
+    uint32_t spp_begin;          /* first global sample index rendered by this call        */
+    uint32_t spp_count;          /* SAMPLE_PER_PIXEL (:21) made a run-time range           */
+    uint32_t max_depth;          /* MAX_SAMPLE_DEPTH (:22), reference value 50             */
+    uint32_t flags;
+    uint64_t seed;               /* Philox key; std::random_device has no seed (Randomizer.h:11) */
+} mirt_render_params;
+
+typedef struct mirt_stats {
+    uint64_t rays;               /* rays traced (sum of the per-bounce queue lengths)      */
+    uint64_t samples;            /* camera samples started                                 */
+    uint64_t depth_hist[64];     /* rays per bounce index (0..63; deeper folded into 63)   */
+    double   device_ms;          /* HIP-event time of the kernels of the call              */
+    double   extend_ms;          /* with option time_launches=1: HIP-event time summed over the
+                                    depth>=1 bounce-kernel launches (the dominant kernel)   */
+    uint32_t bounce_launches;    /* number of bounce-kernel launches (all depths)          */
+    uint32_t batches;
+    double   first_ms;           /* with time_launches=1: same for the depth-0 launches     */
+    uint32_t extend_launches;    /* depth>=1 launches timed into extend_ms                 */
+    uint32_t first_launches;
+} mirt_stats;
+
+typedef struct mirt_ctx mirt_ctx;
+
+/* -- lifecycle ------------------------------------------------------------------------------ */
+/* Replaces `new HomemadeRayTracer(...)` + OnInit (RayTracer.cpp:129-130). */
+int         mirt_create(int device_id, mirt_ctx **out);
+void        mirt_destroy(mirt_ctx *ctx);                 /* HomemadeRayTracer::OnDestroy      */
+const char *mirt_last_error(const mirt_ctx *ctx);        /* ctx may be NULL: last create error */
+int         mirt_device_count(void);
+/* option names: "max_paths" (ray-queue capacity, default 32Mi paths); "time_launches" (0/1:
+ * bracket every bounce-kernel launch with HIP events and report the sums in mirt_stats) */
+int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
+
+/* -- scene ---------------------------------------------------------------------------------- */
+/* Replaces the pointer graph TraceRay walks through World::GetObjectBVHTree()/GetLightSources()
+ * (World.h:28,31). */
+int mirt_upload_scene(mirt_ctx *ctx, const mirt_scene *scene);
+/* Replaces the `const SimpleCamera*` argument of TraceRay (HomemadeRayTracer.h:22). */
+int mirt_set_camera(mirt_ctx *ctx, const mirt_camera *cam);
+
+/* -- render --------------------------------------------------------------------------------- */
+/* HomemadeRayTracer::TraceRay (HomemadeRayTracer.cpp:90-154), device-resident form.
+ * Adds samples [spp_begin, spp_begin+spp_count) of every pixel, in sample order, to d_sum_rgb
+ * (DEVICE pointer, width*height*3 floats, row 0 = top, caller zero-initialises; with
+ * MIRT_FLAG_ONE_SPP the buffer is overwritten).  `stream` is a hipStream_t (NULL = default
+ * stream).  Synchronises the stream before returning when stats != NULL. */
+int mirt_render_device(mirt_ctx *ctx, const mirt_render_params *p, float *d_sum_rgb,
+                       void *stream, mirt_stats *stats);
+/* The tail of TraceRay + OutputImage::Render (HomemadeRayTracer.cpp:134-138, OutputImage.cpp:62-88):
+ * mean over spp_total (skipped for ONE_SPP), per-channel sqrt, clamp, (UINT32)(c*255.0f)&0xFF, A=255.
+ * d_pixels (device, w*h*3 post-gamma floats) and d_rgba8 (device, w*h*4) may each be NULL. */
+int mirt_resolve_device(mirt_ctx *ctx, const float *d_sum_rgb, uint32_t width, uint32_t height,
+                        uint32_t spp_total, uint32_t flags, float *d_pixels, uint8_t *d_rgba8,
+                        void *stream);
+/* Whole TraceRay with host outputs (each nullable): sum of radiance (w*h*3), post-gamma float
+ * pixels (w*h*3, what TraceRay hands to OutputImage::Render) and RGBA8 (w*h*4, OutputImage::m_data). */
+int mirt_render(mirt_ctx *ctx, const mirt_render_params *p, float *h_sum_rgb, float *h_pixels,
+                uint8_t *h_rgba8, mirt_stats *stats);
+
+/* -- function-level entry points (parity tests bind these; host pointers) -------------------- */
+/* AABB::Hit, AABB.cpp:5-21: out[i*nbox+b] = ray i vs box b */
+int mirt_aabb_hit_batch(mirt_ctx *ctx, const float *bmin, const float *bmax, size_t nbox,
+                        const float *org, const float *dir, size_t nray,
+                        float t_min, float t_max, uint8_t *out);
+/* IHitable::Hit of one primitive's instance chain, Hitables.cpp:13-54,93-115,163-173,241-264 */
+int mirt_prim_hit_batch(mirt_ctx *ctx, uint32_t prim, const float *org, const float *dir,
+                        size_t nray, float t_min, float t_max, mirt_hit *out);
+/* SimpleObjectBVHNode::Hit, SimpleObject.cpp:389-406 (flags: MIRT_FLAG_ACCEL_LIST for the list) */
+int mirt_world_hit_batch(mirt_ctx *ctx, const float *org, const float *dir, size_t nray,
+                         float t_min, float t_max, uint32_t flags, mirt_hit *out);
+/* IMaterial::Scatter, Materials.cpp:19-33,99-106,172-217,260-264, with the raw 32-bit draws
+ * (`rd()` of Randomizer.h:14,23) supplied: draws[i*draws_per_ray + k] */
+int mirt_scatter_batch(mirt_ctx *ctx, const mirt_hit *hits, const float *dir_in, size_t n,
+                       const uint32_t *draws, uint32_t draws_per_ray,
+                       uint8_t *out_alive, float *out_atten, float *out_org, float *out_dir,
+                       float *out_emit, uint32_t *consumed);
+/* SimpleCamera::GetRay, SimpleCamera.cpp:55-60, with the raw draws of RandomInUnitDisk supplied */
+int mirt_camera_rays(mirt_ctx *ctx, const float *uv, size_t n,
+                     const uint32_t *draws, uint32_t draws_per_ray,
+                     float *out_org, float *out_dir, uint32_t *consumed);
+/* The RNG source: Philox4x32-10 blocks, out[4*i..] = philox(ctr[4*i..], key) (device-computed) */
+int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32_t key[2], uint32_t *out);
+
+/* Arithmetic self-test of the device's IEEE building blocks (no reference counterpart; parity
+ * tests bind it): op 0 x/y, 1 sqrt(x), 2 x^5 as Schlick evaluates it (Optics.h:31), 3 the [0,1)
+ * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x. */
+int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
+
+/* -- host utilities -------------------------------------------------------------------------- */
+/* PPMImageMaker::OutputRGBA8ToFile, PPMImageMaker.cpp:9-48 (ASCII P3, alpha dropped) */
+int mirt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgba8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

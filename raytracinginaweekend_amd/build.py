@@ -1,0 +1,42 @@
+"""Builds libmirt.so (the HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m raytracinginaweekend_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is required: parity with the reference's
+non-FMA SSE2 arithmetic (and with the CPU oracle) is bit-exact only without contraction.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libmirt.so")
+SOURCES = ["mirt.hip"]
+DEPS = ["mirt.hip", "rt_kernels.h", "rt_device.h", "scene_host.h", os.path.join("..", "..", "include", "mirt.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+         "-Wall", "-Wno-unused-function"]
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

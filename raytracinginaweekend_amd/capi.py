@@ -1,0 +1,247 @@
+"""ctypes binding of libmirt.so (include/mirt.h), the C ABI of the gfx950 path tracer.
+
+There is no CPU fallback: importing works anywhere, but `load()` raises if the HIP library has not
+been built and `Context()` raises if no GPU is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libmirt.so")
+
+PRIM_SPHERE, PRIM_RECT = 0, 1
+MAT_DIFFUSE_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
+CHILD_NONE = -(1 << 31)
+FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_ACCEL_AUTO = 1, 2, 4, 16
+
+f32p = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def axes_pack(a, b, c, rev, rot):
+    return a | (b << 2) | (c << 4) | (int(bool(rev)) << 6) | (int(bool(rot)) << 7)
+
+
+class SceneStruct(C.Structure):
+    """mirt_scene (and, layout-identical, the oracle's orc_scene)."""
+    _fields_ = [
+        ("n_prims", C.c_uint32), ("prim_kind", u32p), ("prim_off", f32p), ("prim_geom", f32p),
+        ("prim_axes", u32p), ("prim_rot", f32p), ("prim_mat", u32p),
+        ("n_objects", C.c_uint32), ("obj_first", u32p), ("obj_count", u32p),
+        ("n_mats", C.c_uint32), ("mat_kind", u32p), ("mat_albedo", f32p), ("mat_fuzz", f32p),
+        ("mat_ior", f32p), ("mat_emit", f32p),
+        ("n_nodes", C.c_uint32), ("node_min", f32p), ("node_max", f32p), ("node_left", i32p),
+        ("node_right", i32p), ("root", C.c_int32), ("ambient", C.c_float * 3),
+    ]
+
+
+class CameraStruct(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("top_left", C.c_float * 3), ("horizontal", C.c_float * 3),
+                ("vertical", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3),
+                ("lens_radius", C.c_float)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp_begin", C.c_uint32),
+                ("spp_count", C.c_uint32), ("max_depth", C.c_uint32), ("flags", C.c_uint32),
+                ("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("depth_hist", C.c_uint64 * 64),
+                ("device_ms", C.c_double), ("extend_ms", C.c_double), ("bounce_launches", C.c_uint32),
+                ("batches", C.c_uint32), ("first_ms", C.c_double), ("extend_launches", C.c_uint32),
+                ("first_launches", C.c_uint32)]
+
+
+HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4"),
+                      ("mat", "<i4"), ("prim", "<i4")])
+
+EXPORTS = [
+    "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
+    "mirt_upload_scene", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render",
+    "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
+    "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_write_ppm",
+]
+
+_lib = None
+
+
+class MirtError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmirt.so; raises MirtError when the HIP extension is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MirtError(f"{LIB_PATH} is missing: build it with `python -m raytracinginaweekend_amd.build` "
+                        "(the path tracer has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.mirt_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.mirt_destroy.argtypes = [vp]; lib.mirt_destroy.restype = None
+    lib.mirt_last_error.argtypes = [vp]; lib.mirt_last_error.restype = C.c_char_p
+    lib.mirt_device_count.argtypes = []
+    lib.mirt_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.mirt_upload_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    lib.mirt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    lib.mirt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    lib.mirt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    lib.mirt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
+    lib.mirt_aabb_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
+    lib.mirt_prim_hit_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
+    lib.mirt_world_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, vp]
+    lib.mirt_scatter_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
+    lib.mirt_camera_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp]
+    lib.mirt_philox_batch.argtypes = [vp, vp, C.c_size_t, vp, vp]
+    lib.mirt_arith_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
+    lib.mirt_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    for name in EXPORTS:
+        if name not in ("mirt_destroy", "mirt_last_error"):
+            getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a if shape is None else a.reshape(shape)
+
+
+class Context:
+    """One mirt_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.mirt_create(int(device), C.byref(h))
+        if rc != 0:
+            raise MirtError(f"mirt_create failed ({rc}): {self.lib.mirt_last_error(None).decode()}")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mirt_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MirtError(f"{what} failed ({rc}): {self.lib.mirt_last_error(self.h).decode()}")
+
+    def set_option(self, name, value):
+        self._ck(self.lib.mirt_set_option(self.h, name.encode(), int(value)), "mirt_set_option")
+
+    def upload_scene(self, scene):
+        """scene: raytracinginaweekend_amd.scene.FlatScene"""
+        st = scene.as_struct()
+        self._ck(self.lib.mirt_upload_scene(self.h, C.byref(st)), "mirt_upload_scene")
+
+    def set_camera(self, cam):
+        self._ck(self.lib.mirt_set_camera(self.h, C.byref(cam)), "mirt_set_camera")
+
+    def render(self, width, height, spp, max_depth=50, seed=0x5EED, flags=FLAG_ACCEL_AUTO, spp_begin=0,
+               want=("sum", "pixels", "rgba8")):
+        p = RenderParams(width, height, spp_begin, spp, max_depth, flags, seed)
+        n = width * height
+        out = {}
+        s = np.empty((height, width, 3), np.float32) if "sum" in want else None
+        px = np.empty((height, width, 3), np.float32) if "pixels" in want else None
+        rg = np.empty((height, width, 4), np.uint8) if "rgba8" in want else None
+        st = Stats()
+        self._ck(self.lib.mirt_render(self.h, C.byref(p), _ptr(s) if s is not None else None,
+                                      _ptr(px) if px is not None else None,
+                                      _ptr(rg) if rg is not None else None, C.byref(st)), "mirt_render")
+        out["sum"], out["pixels"], out["rgba8"], out["stats"] = s, px, rg, st
+        return out
+
+    def render_device(self, params, d_sum_ptr, stream=None, stats=None):
+        self._ck(self.lib.mirt_render_device(self.h, C.byref(params), C.c_void_p(d_sum_ptr),
+                                             C.c_void_p(stream) if stream else None,
+                                             C.byref(stats) if stats is not None else None), "mirt_render_device")
+
+    def resolve_device(self, d_sum_ptr, width, height, spp_total, flags, d_pixels_ptr=None, d_rgba8_ptr=None, stream=None):
+        self._ck(self.lib.mirt_resolve_device(self.h, C.c_void_p(d_sum_ptr), width, height, spp_total, flags,
+                                              C.c_void_p(d_pixels_ptr) if d_pixels_ptr else None,
+                                              C.c_void_p(d_rgba8_ptr) if d_rgba8_ptr else None,
+                                              C.c_void_p(stream) if stream else None), "mirt_resolve_device")
+
+    # ---- function-level entry points -------------------------------------------------------
+    def aabb_hit_batch(self, bmin, bmax, org, dir_, t_min, t_max):
+        bmin, bmax, org, dir_ = _f32(bmin, (-1, 3)), _f32(bmax, (-1, 3)), _f32(org, (-1, 3)), _f32(dir_, (-1, 3))
+        out = np.zeros((org.shape[0], bmin.shape[0]), np.uint8)
+        self._ck(self.lib.mirt_aabb_hit_batch(self.h, _ptr(bmin), _ptr(bmax), bmin.shape[0], _ptr(org), _ptr(dir_),
+                                              org.shape[0], t_min, t_max, _ptr(out)), "mirt_aabb_hit_batch")
+        return out
+
+    def prim_hit_batch(self, prim, org, dir_, t_min, t_max):
+        org, dir_ = _f32(org, (-1, 3)), _f32(dir_, (-1, 3))
+        out = np.zeros(org.shape[0], HIT_DTYPE)
+        self._ck(self.lib.mirt_prim_hit_batch(self.h, prim, _ptr(org), _ptr(dir_), org.shape[0], t_min, t_max, _ptr(out)),
+                 "mirt_prim_hit_batch")
+        return out
+
+    def world_hit_batch(self, org, dir_, t_min, t_max, flags=0):
+        org, dir_ = _f32(org, (-1, 3)), _f32(dir_, (-1, 3))
+        out = np.zeros(org.shape[0], HIT_DTYPE)
+        self._ck(self.lib.mirt_world_hit_batch(self.h, _ptr(org), _ptr(dir_), org.shape[0], t_min, t_max, flags, _ptr(out)),
+                 "mirt_world_hit_batch")
+        return out
+
+    def scatter_batch(self, hits, dir_in, draws):
+        hits = np.ascontiguousarray(hits, HIT_DTYPE); dir_in = _f32(dir_in, (-1, 3))
+        draws = np.ascontiguousarray(draws, np.uint32); n = hits.shape[0]
+        alive = np.zeros(n, np.uint8); att = np.zeros((n, 3), np.float32); org = np.zeros((n, 3), np.float32)
+        dr = np.zeros((n, 3), np.float32); em = np.zeros((n, 3), np.float32); used = np.zeros(n, np.uint32)
+        self._ck(self.lib.mirt_scatter_batch(self.h, _ptr(hits), _ptr(dir_in), n, _ptr(draws), draws.shape[1], _ptr(alive),
+                                             _ptr(att), _ptr(org), _ptr(dr), _ptr(em), _ptr(used)), "mirt_scatter_batch")
+        return dict(alive=alive, atten=att, org=org, dir=dr, emit=em, consumed=used)
+
+    def camera_rays(self, uv, draws):
+        uv = _f32(uv, (-1, 2)); draws = np.ascontiguousarray(draws, np.uint32); n = uv.shape[0]
+        org = np.zeros((n, 3), np.float32); dr = np.zeros((n, 3), np.float32); used = np.zeros(n, np.uint32)
+        self._ck(self.lib.mirt_camera_rays(self.h, _ptr(uv), n, _ptr(draws), draws.shape[1], _ptr(org), _ptr(dr), _ptr(used)),
+                 "mirt_camera_rays")
+        return dict(org=org, dir=dr, consumed=used)
+
+    def philox_batch(self, ctr, key):
+        ctr = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4); key = np.ascontiguousarray(key, np.uint32)
+        out = np.zeros_like(ctr)
+        self._ck(self.lib.mirt_philox_batch(self.h, _ptr(ctr), ctr.shape[0], _ptr(key), _ptr(out)), "mirt_philox_batch")
+        return out
+
+    def arith_batch(self, op, x, y=None):
+        x = np.ascontiguousarray(x).view(np.float32).ravel()
+        yy = None if y is None else np.ascontiguousarray(y, np.float32).ravel()
+        out = np.zeros_like(x)
+        self._ck(self.lib.mirt_arith_batch(self.h, op, _ptr(x), _ptr(yy) if yy is not None else None, x.shape[0], _ptr(out)),
+                 "mirt_arith_batch")
+        return out
+
+
+def write_ppm(path, rgba8):
+    """PPMImageMaker::OutputRGBA8ToFile (ASCII P3)."""
+    rgba8 = np.ascontiguousarray(rgba8, np.uint8)
+    h, w = rgba8.shape[:2]
+    rc = load().mirt_write_ppm(os.fsencode(path), w, h, _ptr(rgba8))
+    if rc != 0:
+        raise MirtError(f"mirt_write_ppm failed ({rc})")

@@ -1,0 +1,520 @@
+// mirt.hip -- C ABI of libmirt.so (include/mirt.h): context, scene upload, the wavefront render
+// loop that drives the gfx950 kernels of rt_kernels.h, and the function-level parity entry points.
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "rt_kernels.h"
+#include "scene_host.h"
+
+using namespace mirt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int ensure(size_t n)
+    {
+        if (n <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return -1; }
+        bytes = n; return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct mirt_ctx {
+    int device = 0;
+    std::string err;
+    bool have_scene = false, have_camera = false;
+    SceneDev sc{};
+    uint32_t lds_bytes = 0;
+    bool prims_in_lds = false;
+    mirt_camera cam{};
+    DevBuf d_prims, d_nodes, d_objs, d_mats;
+    DevBuf d_queues, d_rad, d_counts, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
+    uint64_t max_paths = 32ull << 20;
+    bool time_launches = false;
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 256;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return MIRT_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+static int fail(mirt_ctx *c, int code, const std::string &msg) { c->err = msg; return code; }
+
+extern "C" int mirt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int mirt_create(int device_id, mirt_ctx **out)
+{
+    if (!out) { g_create_error = "mirt_create: out is NULL"; return MIRT_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_create_error = "mirt_create: no HIP device (the path tracer has no CPU fallback)"; return MIRT_ERR_HIP; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "mirt_create: device id out of range"; return MIRT_ERR_ARG; }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e); return MIRT_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) { g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e); return MIRT_ERR_HIP; }
+    mirt_ctx *c = new mirt_ctx();
+    c->device = device_id;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_create_error = "hipEventCreate failed"; delete c; return MIRT_ERR_HIP; }
+    *out = c;
+    return MIRT_OK;
+}
+
+extern "C" void mirt_destroy(mirt_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    for (DevBuf *b : bufs) b->release();
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+extern "C" const char *mirt_last_error(const mirt_ctx *c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
+{
+    if (!c || !name) return MIRT_ERR_ARG;
+    if (!strcmp(name, "max_paths")) {
+        if (value < 1024 || value > (1ll << 31)) return fail(c, MIRT_ERR_ARG, "max_paths must be in [1024, 2^31]");
+        c->max_paths = (uint64_t)value;
+        return MIRT_OK;
+    }
+    if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
+    return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
+}
+
+// ------------------------------------------------------------------------------------------ scene
+extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
+{
+    if (!c || !s) return MIRT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::string why = host::validate(*s);
+    if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
+    host::Tree tree;
+    why = host::prepare_tree(*s, tree);
+    if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
+    if (tree.depth > 60) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: BVH deeper than 60 levels");
+
+    std::vector<PrimRec> prims(s->n_prims);
+    for (uint32_t p = 0; p < s->n_prims; ++p) {
+        PrimRec &r = prims[p];
+        memset(&r, 0, sizeof r);
+        for (int i = 0; i < 3; ++i) r.off[i] = s->prim_off[3 * (size_t)p + i];
+        const float *g = s->prim_geom + 5 * (size_t)p;
+        r.mat = s->prim_mat[p];
+        if (s->prim_kind[p] == MIRT_PRIM_SPHERE) {
+            r.info = 0;
+            r.g[0] = g[0]; r.g[1] = 1.f / g[0]; r.g[2] = g[0] * g[0];      // Vec3.h:85-88, Hitables.cpp:23
+        } else {
+            uint32_t ax = s->prim_axes[p];
+            const float *q = s->prim_rot + 6 * (size_t)p;
+            bool chain = (ax >> 7) & 1, live = false;
+            if (chain) for (int k = 0; k < 3; ++k) live |= !(q[2 * k] == 0.0f && q[2 * k + 1] == 1.0f);
+            r.info = 1u | ((ax & 3) << 1) | (((ax >> 2) & 3) << 3) | (((ax >> 4) & 3) << 5) | (((ax >> 6) & 1) << 7) | ((live ? 1u : 0u) << 8);
+            for (int i = 0; i < 5; ++i) r.g[i] = g[i];
+            for (int i = 0; i < 6; ++i) r.rot[i] = chain ? q[i] : ((i & 1) ? 1.0f : 0.0f);
+        }
+    }
+    std::vector<NodeRec> nodes(tree.box.size());
+    for (size_t i = 0; i < nodes.size(); ++i) {
+        for (int a = 0; a < 3; ++a) { nodes[i].mn[a] = tree.box[i].mn[a]; nodes[i].mx[a] = tree.box[i].mx[a]; }
+        nodes[i].left = tree.left[i]; nodes[i].right = tree.right[i];
+    }
+    std::vector<uint2> objs(s->n_objects);
+    for (uint32_t o = 0; o < s->n_objects; ++o) objs[o] = make_uint2(s->obj_first[o], s->obj_count[o]);
+    std::vector<MatRec> mats(s->n_mats);
+    for (uint32_t m = 0; m < s->n_mats; ++m) {
+        MatRec &r = mats[m]; memset(&r, 0, sizeof r);
+        r.kind = s->mat_kind[m]; r.fuzz = s->mat_fuzz[m]; r.ior = s->mat_ior[m];
+        for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
+    }
+    if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
+        c->d_objs.ensure(objs.size() * sizeof(uint2)) || c->d_mats.ensure(mats.size() * sizeof(MatRec)))
+        return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
+    HIPCHK(c, hipMemcpy(c->d_prims.p, prims.data(), prims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_objs.p, objs.data(), objs.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_mats.p, mats.data(), mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
+
+    SceneDev &d = c->sc;
+    d.prims = (const PrimRec *)c->d_prims.p; d.n_prims = s->n_prims;
+    d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
+    d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;
+    d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
+    d.root = tree.root;
+    for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];
+    // LDS plan, <= 40 KiB per workgroup so four workgroups share a CU's 160 KiB
+    const uint32_t budget = 40u * 1024u;
+    d.stack_depth = tree.depth + 1;
+    uint32_t used = d.stack_depth * MIRT_BLOCK * 4u;
+    d.lds_mats = (s->n_mats * sizeof(MatRec) <= 6u * 1024u) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
+    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 16u * 1024u;
+    d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
+    uint32_t room = used < budget ? (budget - used) / (uint32_t)sizeof(NodeRec) : 0u;
+    d.lds_nodes = std::min<uint32_t>(room, d.n_nodes); used += d.lds_nodes * (uint32_t)sizeof(NodeRec);
+    c->lds_bytes = used;
+    c->have_scene = true;
+    return MIRT_OK;
+}
+
+extern "C" int mirt_set_camera(mirt_ctx *c, const mirt_camera *cam)
+{
+    if (!c || !cam) return MIRT_ERR_ARG;
+    c->cam = *cam; c->have_camera = true;
+    return MIRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ render
+static bool use_list(const mirt_ctx *c, uint32_t flags)
+{
+    if (flags & MIRT_FLAG_ACCEL_LIST) return true;
+    if (flags & MIRT_FLAG_ACCEL_AUTO) return c->sc.n_prims <= 16 && c->prims_in_lds;
+    return false;
+}
+
+template <bool FIRST>
+static void launch_bounce(const mirt_ctx *c, bool list, const BounceArgs &a, uint32_t grid, hipStream_t st)
+{
+    const uint32_t lds = c->lds_bytes;
+    if (list) {
+        if (c->prims_in_lds) hipLaunchKernelGGL((k_bounce<FIRST, 0, true>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
+        else hipLaunchKernelGGL((k_bounce<FIRST, 0, false>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
+    } else {
+        if (c->prims_in_lds) hipLaunchKernelGGL((k_bounce<FIRST, 1, true>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
+        else hipLaunchKernelGGL((k_bounce<FIRST, 1, false>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
+    }
+}
+
+static PathQ carve_queue(float *base, size_t cap)
+{
+    PathQ q;
+    q.ox = base; q.oy = base + cap; q.oz = base + 2 * cap; q.dx = base + 3 * cap; q.dy = base + 4 * cap; q.dz = base + 5 * cap;
+    q.tr = base + 6 * cap; q.tg = base + 7 * cap; q.tb = base + 8 * cap;
+    q.pix = (uint32_t *)(base + 9 * cap); q.smp = (uint32_t *)(base + 10 * cap);
+    return q;
+}
+
+extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream, mirt_stats *stats)
+{
+    if (!c || !p || !d_sum) return MIRT_ERR_ARG;
+    if (!c->have_scene || !c->have_camera) return fail(c, MIRT_ERR_STATE, "mirt_render_device: upload a scene and set a camera first");
+    if (!p->width || !p->height) return fail(c, MIRT_ERR_ARG, "mirt_render_device: empty image");
+    const uint64_t npix_total = (uint64_t)p->width * p->height;
+    if (npix_total > (1ull << 31)) return fail(c, MIRT_ERR_ARG, "mirt_render_device: image larger than 2^31 pixels");
+    if (p->max_depth > 4096) return fail(c, MIRT_ERR_ARG, "mirt_render_device: max_depth > 4096");
+    const bool one_spp = p->flags & MIRT_FLAG_ONE_SPP;
+    const uint32_t spp_count = one_spp ? 1u : p->spp_count;
+    const uint32_t spp_begin = one_spp ? 0u : p->spp_begin;
+    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: sample index overflows 32 bits");
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (spp_count == 0) return MIRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool list = use_list(c, p->flags);
+
+    // batch geometry: npix_b pixels x S samples <= capacity
+    const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
+    const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
+    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
+    const size_t capq = (size_t)npix_b * S;
+    const uint32_t n_pix_tiles = (uint32_t)((npix_total + npix_b - 1) / npix_b);
+    const uint32_t n_s_tiles = (spp_count + S - 1) / S;
+    const uint32_t n_batches = n_pix_tiles * n_s_tiles;
+    const uint32_t n_depth = p->max_depth + 2;            // counts[d] = paths entering bounce d
+
+    if (c->d_queues.ensure(2 * 11 * capq * sizeof(float)) || c->d_rad.ensure(capq * sizeof(float4)) ||
+        c->d_counts.ensure((size_t)n_batches * n_depth * sizeof(uint32_t)))
+        return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the ray queues failed (lower the max_paths option)");
+    PathQ q[2] = { carve_queue((float *)c->d_queues.p, capq), carve_queue((float *)c->d_queues.p + 11 * capq, capq) };
+    uint32_t *counts = (uint32_t *)c->d_counts.p;
+    HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)n_batches * n_depth * sizeof(uint32_t), st));
+    if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
+
+    BounceArgs a{};
+    a.sc = c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
+    a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+    const uint32_t max_grid = (uint32_t)c->n_cu * 8u;
+    uint32_t launches = 0, batch = 0;
+    const bool timed = stats && c->time_launches;
+    std::vector<uint8_t> ev_first;       // per timed launch: 1 = depth 0
+    if (timed) {
+        size_t need = 2 * (size_t)n_batches * (p->max_depth + 1);
+        while (c->ev_pool.size() < need) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
+    }
+    for (uint32_t pt = 0; pt < n_pix_tiles; ++pt) {
+        const uint32_t pix0 = pt * npix_b;
+        const uint32_t np = (uint32_t)std::min<uint64_t>(npix_b, npix_total - pix0);
+        for (uint32_t stile = 0; stile < n_s_tiles; ++stile, ++batch) {
+            const uint32_t s0 = spp_begin + stile * S;
+            const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
+            const uint32_t n_first = np * ns;
+            uint32_t *cnt = counts + (size_t)batch * n_depth;
+            a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_first = n_first;
+            const uint32_t grid = std::min<uint32_t>((n_first + MIRT_BLOCK - 1) / MIRT_BLOCK, max_grid);
+            for (uint32_t d = 0; d <= p->max_depth; ++d) {
+                a.depth = d;
+                a.in = q[d & 1]; a.out = q[(d + 1) & 1];
+                a.count_in = cnt + d; a.count_out = cnt + d + 1;
+                if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size()], st));
+                if (d == 0) launch_bounce<true>(c, list, a, grid, st);
+                else launch_bounce<false>(c, list, a, grid, st);
+                if (timed) { HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size() + 1], st)); ev_first.push_back(d == 0); }
+                ++launches;
+                if (p->flags & MIRT_FLAG_NORMAL_DISPLAY) break;      // every path ends at its first vertex
+            }
+            hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
+                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    if (stats) {
+        HIPCHK(c, hipEventRecord(c->ev1, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        std::vector<uint32_t> h((size_t)n_batches * n_depth);
+        HIPCHK(c, hipMemcpy(h.data(), counts, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        stats->device_ms = ms; stats->bounce_launches = launches; stats->batches = n_batches;
+        for (size_t i = 0; i < ev_first.size(); ++i) {
+            float t = 0; HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
+            if (ev_first[i]) { stats->first_ms += t; stats->first_launches++; } else { stats->extend_ms += t; stats->extend_launches++; }
+        }
+        stats->samples = npix_total * spp_count;
+        stats->rays = stats->samples;                                  // bounce 0 traces one ray per sample
+        stats->depth_hist[0] = stats->samples;
+        for (uint32_t b = 0; b < n_batches; ++b)
+            for (uint32_t d = 1; d <= p->max_depth; ++d) {
+                uint64_t v = h[(size_t)b * n_depth + d];
+                stats->rays += v; stats->depth_hist[d < 63 ? d : 63] += v;
+            }
+    }
+    return MIRT_OK;
+}
+
+extern "C" int mirt_resolve_device(mirt_ctx *c, const float *d_sum, uint32_t w, uint32_t h, uint32_t spp_total, uint32_t flags,
+                                   float *d_pixels, uint8_t *d_rgba8, void *stream)
+{
+    if (!c || !d_sum || !w || !h) return MIRT_ERR_ARG;
+    if (!(flags & MIRT_FLAG_ONE_SPP) && spp_total == 0) return fail(c, MIRT_ERR_ARG, "mirt_resolve_device: spp_total is 0");
+    if (((uintptr_t)d_rgba8) & 3) return fail(c, MIRT_ERR_ARG, "mirt_resolve_device: rgba8 must be 4-byte aligned");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t npix = w * h;
+    hipLaunchKernelGGL(k_resolve, dim3((npix + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, (hipStream_t)stream,
+                       d_sum, npix, spp_total, flags, d_pixels, (uint32_t *)d_rgba8);
+    HIPCHK(c, hipGetLastError());
+    return MIRT_OK;
+}
+
+extern "C" int mirt_render(mirt_ctx *c, const mirt_render_params *p, float *h_sum, float *h_pixels, uint8_t *h_rgba8, mirt_stats *stats)
+{
+    if (!c || !p) return MIRT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)p->width * p->height;
+    if (!npix) return fail(c, MIRT_ERR_ARG, "mirt_render: empty image");
+    if (c->d_tmp_sum.ensure(npix * 3 * sizeof(float)) || c->d_tmp_pix.ensure(npix * 3 * sizeof(float)) || c->d_tmp_rgba.ensure(npix * 4))
+        return fail(c, MIRT_ERR_NOMEM, "mirt_render: hipMalloc failed");
+    HIPCHK(c, hipMemset(c->d_tmp_sum.p, 0, npix * 3 * sizeof(float)));
+    int rc = mirt_render_device(c, p, (float *)c->d_tmp_sum.p, nullptr, stats);
+    if (rc) return rc;
+    rc = mirt_resolve_device(c, (const float *)c->d_tmp_sum.p, p->width, p->height, p->spp_count, p->flags,
+                             (float *)c->d_tmp_pix.p, (uint8_t *)c->d_tmp_rgba.p, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (h_sum) HIPCHK(c, hipMemcpy(h_sum, c->d_tmp_sum.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_pixels) HIPCHK(c, hipMemcpy(h_pixels, c->d_tmp_pix.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_rgba8) HIPCHK(c, hipMemcpy(h_rgba8, c->d_tmp_rgba.p, npix * 4, hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ function-level entry points
+namespace {
+struct Tmp {   // RAII device scratch for the batch hooks
+    std::vector<void *> v;
+    ~Tmp() { for (void *p : v) (void)hipFree(p); }
+    template <class T> T *up(const T *h, size_t n) { void *d = nullptr; if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr; v.push_back(d); if (h && n) (void)hipMemcpy(d, h, n * sizeof(T), hipMemcpyHostToDevice); return (T *)d; }
+};
+}
+#define NEED(ptr) if (!(ptr)) return fail(c, MIRT_ERR_NOMEM, "hipMalloc failed in a batch entry point")
+#define CHECK_N(n) if ((n) > 0x7FFFFFFFull) return fail(c, MIRT_ERR_ARG, "batch too large")
+
+extern "C" int mirt_aabb_hit_batch(mirt_ctx *c, const float *bmin, const float *bmax, size_t nbox, const float *org, const float *dir,
+                                   size_t nray, float t_min, float t_max, uint8_t *out)
+{
+    if (!c || !bmin || !bmax || !org || !dir || !out) return MIRT_ERR_ARG;
+    if (!nray || !nbox) return MIRT_OK;
+    CHECK_N(nray); CHECK_N(nbox);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *dmin = t.up(bmin, 3 * nbox), *dmax = t.up(bmax, 3 * nbox), *dorg = t.up(org, 3 * nray), *ddir = t.up(dir, 3 * nray);
+    uint8_t *dout = t.up<uint8_t>(nullptr, nray * nbox);
+    NEED(dmin && dmax && dorg && ddir && dout);
+    hipLaunchKernelGGL(k_aabb_batch, dim3((uint32_t)((nray + 255) / 256)), dim3(256), 0, 0, dmin, dmax, (uint32_t)nbox, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, nray * nbox, hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_prim_hit_batch(mirt_ctx *c, uint32_t prim, const float *org, const float *dir, size_t nray, float t_min, float t_max, mirt_hit *out)
+{
+    if (!c || !org || !dir || !out) return MIRT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_prim_hit_batch: no scene");
+    if (prim >= c->sc.n_prims) return fail(c, MIRT_ERR_ARG, "mirt_prim_hit_batch: primitive out of range");
+    if (!nray) return MIRT_OK;
+    CHECK_N(nray);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *dorg = t.up(org, 3 * nray), *ddir = t.up(dir, 3 * nray);
+    mirt_hit *dout = t.up<mirt_hit>(nullptr, nray);
+    NEED(dorg && ddir && dout);
+    hipLaunchKernelGGL(k_prim_hit_batch, dim3((uint32_t)((nray + 255) / 256)), dim3(256), 0, 0, c->sc, prim, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, nray * sizeof(mirt_hit), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_world_hit_batch(mirt_ctx *c, const float *org, const float *dir, size_t nray, float t_min, float t_max, uint32_t flags, mirt_hit *out)
+{
+    if (!c || !org || !dir || !out) return MIRT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_world_hit_batch: no scene");
+    if (!nray) return MIRT_OK;
+    CHECK_N(nray);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *dorg = t.up(org, 3 * nray), *ddir = t.up(dir, 3 * nray);
+    mirt_hit *dout = t.up<mirt_hit>(nullptr, nray);
+    NEED(dorg && ddir && dout);
+    dim3 g((uint32_t)((nray + MIRT_BLOCK - 1) / MIRT_BLOCK)), b(MIRT_BLOCK);
+    const bool list = use_list(c, flags);
+    if (list) {
+        if (c->prims_in_lds) hipLaunchKernelGGL((k_world_hit_batch<0, true>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+        else hipLaunchKernelGGL((k_world_hit_batch<0, false>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+    } else {
+        if (c->prims_in_lds) hipLaunchKernelGGL((k_world_hit_batch<1, true>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+        else hipLaunchKernelGGL((k_world_hit_batch<1, false>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, nray * sizeof(mirt_hit), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_scatter_batch(mirt_ctx *c, const mirt_hit *hits, const float *dir_in, size_t n, const uint32_t *draws, uint32_t dpr,
+                                  uint8_t *out_alive, float *out_atten, float *out_org, float *out_dir, float *out_emit, uint32_t *consumed)
+{
+    if (!c || !hits || !dir_in || !draws || !out_alive || !out_atten || !out_org || !out_dir || !out_emit) return MIRT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_scatter_batch: no scene");
+    if (!n) return MIRT_OK;
+    CHECK_N(n);
+    for (size_t i = 0; i < n; ++i) if (hits[i].mat < 0 || (uint32_t)hits[i].mat >= c->sc.n_mats) return fail(c, MIRT_ERR_ARG, "mirt_scatter_batch: hit with bad material index");
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    mirt_hit *dh = t.up(hits, n); float *dd = t.up(dir_in, 3 * n); uint32_t *dr = t.up(draws, n * (size_t)dpr);
+    uint8_t *da = t.up<uint8_t>(nullptr, n); float *dat = t.up<float>(nullptr, 3 * n), *dorg = t.up<float>(nullptr, 3 * n), *ddir = t.up<float>(nullptr, 3 * n), *dem = t.up<float>(nullptr, 3 * n);
+    uint32_t *dc = t.up<uint32_t>(nullptr, n);
+    NEED(dh && dd && dr && da && dat && dorg && ddir && dem && dc);
+    hipLaunchKernelGGL(k_scatter_batch, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, c->sc, dh, dd, (uint32_t)n, dr, dpr, da, dat, dorg, ddir, dem, dc);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out_alive, da, n, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_atten, dat, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_org, dorg, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_dir, ddir, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_emit, dem, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (consumed) HIPCHK(c, hipMemcpy(consumed, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_camera_rays(mirt_ctx *c, const float *uv, size_t n, const uint32_t *draws, uint32_t dpr, float *out_org, float *out_dir, uint32_t *consumed)
+{
+    if (!c || !uv || !draws || !out_org || !out_dir) return MIRT_ERR_ARG;
+    if (!c->have_camera) return fail(c, MIRT_ERR_STATE, "mirt_camera_rays: no camera");
+    if (!n) return MIRT_OK;
+    CHECK_N(n);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *duv = t.up(uv, 2 * n); uint32_t *dr = t.up(draws, n * (size_t)dpr);
+    float *dorg = t.up<float>(nullptr, 3 * n), *ddir = t.up<float>(nullptr, 3 * n); uint32_t *dc = t.up<uint32_t>(nullptr, n);
+    NEED(duv && dr && dorg && ddir && dc);
+    hipLaunchKernelGGL(k_camera_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, c->cam, duv, (uint32_t)n, dr, dpr, dorg, ddir, dc);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out_org, dorg, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out_dir, ddir, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
+    if (consumed) HIPCHK(c, hipMemcpy(consumed, dc, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_philox_batch(mirt_ctx *c, const uint32_t *ctr, size_t n, const uint32_t key[2], uint32_t *out)
+{
+    if (!c || !ctr || !key || !out) return MIRT_ERR_ARG;
+    if (!n) return MIRT_OK;
+    CHECK_N(n);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    uint32_t *dc = t.up(ctr, 4 * n), *dout = t.up<uint32_t>(nullptr, 4 * n);
+    NEED(dc && dout);
+    hipLaunchKernelGGL(k_philox_batch, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, dc, (uint32_t)n, key[0], key[1], dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_arith_batch(mirt_ctx *c, uint32_t op, const float *x, const float *y, size_t n, float *out)
+{
+    if (!c || !x || !out || op > 4) return MIRT_ERR_ARG;
+    if (!n) return MIRT_OK;
+    CHECK_N(n);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *dx = t.up(x, n), *dy = y ? t.up(y, n) : nullptr, *dout = t.up<float>(nullptr, n);
+    NEED(dx && dout && (!y || dy));
+    hipLaunchKernelGGL(k_arith, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, op, dx, dy, (uint32_t)n, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(out, dout, n * sizeof(float), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ PPMImageMaker.cpp:9-48
+extern "C" int mirt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgba8)
+{
+    if (!path || !rgba8) return MIRT_ERR_ARG;
+    FILE *f = fopen(path, "w");
+    if (!f) return MIRT_ERR_ARG;
+    std::string buf;
+    buf.reserve(1 << 20);
+    char line[64];
+    int n = snprintf(line, sizeof line, "P3\n%u %u\n255\n", width, height);
+    buf.append(line, n);
+    for (size_t i = 0; i < (size_t)width * height; ++i) {
+        n = snprintf(line, sizeof line, "%u %u %u\n", (unsigned)rgba8[4 * i], (unsigned)rgba8[4 * i + 1], (unsigned)rgba8[4 * i + 2]);
+        buf.append(line, n);
+        if (buf.size() > (1 << 20) - 64) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); }
+    }
+    fwrite(buf.data(), 1, buf.size(), f);
+    return fclose(f) == 0 ? MIRT_OK : MIRT_ERR_ARG;
+}

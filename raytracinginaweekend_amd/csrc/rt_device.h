@@ -1,0 +1,355 @@
+// rt_device.h -- gfx950 device functions of the wavefront path tracer: float3 math in the
+// reference's operation order, Philox4x32-10, the Randomizer mappings, intersection and scatter.
+//
+// Everything here is compiled with -ffp-contract=off: the reference is MSVC /fp:precise on the
+// DirectXMath SSE2 path (no FMA), and parity with the CPU oracle is bit-exact only if no
+// multiply-add is contracted.  Divisions and square roots are IEEE correctly rounded (hipcc's
+// default -fhip-fp32-correctly-rounded-divide-sqrt).  Explicit fma() calls are used only where
+// the oracle uses them too (the exact-quotient trick in map_pm1).
+//
+// File:line citations are relative to /root/reference/RayTracer/RayTracer/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mirt.h"
+
+namespace mirt {
+
+// ----------------------------------------------------------------------------- Vec3.h / Ray.h
+struct f3 { float x, y, z; };
+struct Ray { f3 o, d; };
+
+__device__ __forceinline__ f3 mk(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }   // Vec3.h:55-58
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }   // Vec3.h:60-63
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }   // Vec3.h:65-68
+__device__ __forceinline__ f3 scale(f3 a, float f) { return mk(a.x * f, a.y * f, a.z * f); }          // Vec3.h:75-83
+__device__ __forceinline__ f3 neg(f3 a) { return mk(0.0f - a.x, 0.0f - a.y, 0.0f - a.z); }            // Vec3.h:21 (0 - v)
+__device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }      // Vec3.h:90-93
+__device__ __forceinline__ float get(f3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ void set(f3 &a, uint32_t i, float f) { if (i == 0) a.x = f; else if (i == 1) a.y = f; else a.z = f; }
+__device__ __forceinline__ f3 normalize(f3 a)                                                         // Vec3.h:100-103
+{
+    float l2 = dot(a, a);
+    float l = __builtin_sqrtf(l2);
+    if (l == 0.0f) return mk(0.0f, 0.0f, 0.0f);
+    if (__builtin_isinf(l2)) { float q = __builtin_nanf(""); return mk(q, q, q); }
+    return mk(a.x / l, a.y / l, a.z / l);
+}
+__device__ __forceinline__ f3 ray_at(f3 o, f3 d, float t) { return o + scale(d, t); }                 // Ray.h:14
+
+// ----------------------------------------------------------------------------- RNG source
+// Philox4x32-10 (Salmon et al. SC'11) replaces std::random_device (Randomizer.h:11,22).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Randomizer.h:9-17 with (min,max) = (0,1): (float)((double)raw / 2^32).  u32 -> f32 conversion
+// rounds to nearest-even exactly like double -> float of the exact quotient, and the power-of-two
+// scale is exact, so no f64 is needed.  Can return 1.0f for raw >= 2^32-128, as the reference can.
+__device__ __forceinline__ float map_unorm(uint32_t raw) { return (float)raw * 0x1p-32f; }
+
+// Randomizer.h:20-26 with (min,max) = (-1,1): r = raw / 4294967295.0; r = r*2.0 + (-1.0); (float)r.
+// The IEEE quotient is produced without a divide (Markstein: q0 = a*R, q = fma(fma(-q0,D,a),R,q0),
+// R = RN(1/D)); tests/test_oracle.py checks all 2^32 inputs against a true divide.  r*2.0 is exact
+// so fma(r,2,-1) rounds once, exactly as the separate multiply and add do.
+__device__ __forceinline__ float map_pm1(uint32_t raw)
+{
+    const double D = 4294967295.0, R = 1.0 / 4294967295.0;
+    double a = (double)raw;
+    double q0 = a * R;
+    double q = __builtin_fma(__builtin_fma(-q0, D, a), R, q0);
+    return (float)__builtin_fma(q, 2.0, -1.0);
+}
+
+#define MIRT_REJECT_CAP 64   // same cap as the oracle's ORC_REJECT_CAP
+
+// Keyed draw source: counter = (pixel, sample, stage, block), key = seed.
+// stage 0 = camera (block 0 = jitter u, jitter v, disk iteration 0; block k>=1 = disk iterations
+// 2k-1, 2k); stage 1+depth = scatter at that depth (block i = rejection iteration i, lanes 0..2;
+// the dielectric's single draw is block 0 lane 0).
+struct PhiloxKeyed {
+    // lazy: a stateless keyed source lets Lambertian skip its draws when the path is absorbed
+    // anyway (Materials.cpp:32 decides independently of the draw); the result is unchanged.
+    static constexpr bool lazy = true;
+    uint32_t pixel, sample, stage, k0, k1;
+    __device__ __forceinline__ void block(uint32_t b, uint32_t out[4]) const { philox4x32_10(pixel, sample, stage, b, k0, k1, out); }
+};
+// Explicit raw draws (function-level parity tests): consumed in call order.
+struct StreamDraws {
+    static constexpr bool lazy = false;   // consume draws exactly where the reference calls rd()
+    const uint32_t *p; uint32_t n, pos;
+    __device__ __forceinline__ uint32_t next() { uint32_t r = pos < n ? p[pos] : 0u; ++pos; return r; }
+};
+
+// Randomizer.h:40-48 (RomdomInUnitSphere)
+__device__ __forceinline__ f3 in_unit_sphere(const PhiloxKeyed &g)
+{
+    f3 p = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t it = 0; it < MIRT_REJECT_CAP; ++it) {
+        uint32_t r[4]; g.block(it, r);
+        p = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
+        if (!(dot(p, p) >= 1.0f)) break;
+    }
+    return p;
+}
+__device__ __forceinline__ f3 in_unit_sphere(StreamDraws &g)
+{
+    f3 p = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t it = 0; it < MIRT_REJECT_CAP; ++it) {
+        float x = map_pm1(g.next()), y = map_pm1(g.next()), z = map_pm1(g.next());
+        p = mk(x, y, z);
+        if (!(dot(p, p) >= 1.0f)) break;
+    }
+    return p;
+}
+__device__ __forceinline__ float scatter_unorm(const PhiloxKeyed &g) { uint32_t r[4]; g.block(0, r); return map_unorm(r[0]); }
+__device__ __forceinline__ float scatter_unorm(StreamDraws &g) { return map_unorm(g.next()); }
+
+// ----------------------------------------------------------------------------- scene records
+// Device layout (packed from the SoA arrays of mirt_scene at upload):
+struct PrimRec {            // 64 B
+    float    off[3];        // TranslatedInstance::m_offset
+    uint32_t info;          // bit0 kind, bits1-2 aAxis, 3-4 bAxis, 5-6 cAxis, 7 reverse, 8 rotation active
+    float    g[5];          // sphere: r, 1.f/r, r*r ; rect: a0,a1,b0,b1,c
+    uint32_t mat;
+    float    rot[6];        // sinx,cosx,siny,cosy,sinz,cosz
+};
+struct NodeRec {            // 32 B: one aligned 32-byte sector per (per-lane, divergent) node fetch
+    float   mn[3]; int32_t left;
+    float   mx[3]; int32_t right;
+};
+struct MatRec {             // 48 B
+    uint32_t kind; float albedo[3];
+    float    fuzz, ior, emit[3];
+    float    pad[3];
+};
+#define PI_KIND(i)   ((i) & 1u)
+#define PI_AAX(i)    (((i) >> 1) & 3u)
+#define PI_BAX(i)    (((i) >> 3) & 3u)
+#define PI_CAX(i)    (((i) >> 5) & 3u)
+#define PI_REV(i)    (((i) >> 7) & 1u)
+#define PI_ROT(i)    (((i) >> 8) & 1u)
+
+struct Hit { float t; f3 pos, nrm; float u, v; int32_t mat, prim; };
+
+// ----------------------------------------------------------------------------- AABB.cpp:5-21
+// min/max are the Win32 compare-select macros (AABB.cpp:15-16), not fminf/fmaxf.
+__device__ __forceinline__ bool aabb_hit(const float mn[3], const float mx[3], f3 o, f3 d, float t_min, float t_max)
+{
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a) {
+        float invD = 1.0f / get(d, a);
+        float t0 = (mn[a] - get(o, a)) * invD;
+        float t1 = (mx[a] - get(o, a)) * invD;
+        if (invD < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = (t0 > t_min) ? t0 : t_min;
+        t_max = (t1 < t_max) ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    return true;
+}
+
+// ----------------------------------------------------------------------------- Hitables.cpp
+// RotatedInstance tables, Hitables.cpp:188-206
+__device__ __forceinline__ void rot_axes(uint32_t ax, uint32_t &a, uint32_t &b, float &OP)
+{
+    if (ax == 0) { a = 1; b = 2; OP = -1.0f; }
+    else if (ax == 1) { a = 0; b = 2; OP = 1.0f; }
+    else { a = 0; b = 1; OP = -1.0f; }
+}
+// Hitables.cpp:244-250
+__device__ __forceinline__ void rot_in(f3 &o, f3 &d, uint32_t ax, float s, float c)
+{
+    uint32_t a, b; float OP; rot_axes(ax, a, b, OP);
+    float opp = -OP;
+    f3 o0 = o, d0 = d;
+    set(o, a, c * get(o0, a) + opp * s * get(o0, b));
+    set(o, b, -opp * s * get(o0, a) + c * get(o0, b));
+    set(d, a, c * get(d0, a) + opp * s * get(d0, b));
+    set(d, b, -opp * s * get(d0, a) + c * get(d0, b));
+}
+// Hitables.cpp:253-260
+__device__ __forceinline__ void rot_out(f3 &p, f3 &n, uint32_t ax, float s, float c)
+{
+    uint32_t a, b; float OP; rot_axes(ax, a, b, OP);
+    f3 p0 = p, n0 = n;
+    set(p, a, c * get(p0, a) + OP * s * get(p0, b));
+    set(p, b, -OP * s * get(p0, a) + c * get(p0, b));
+    set(n, a, c * get(n0, a) + OP * s * get(n0, b));
+    set(n, b, -OP * s * get(n0, a) + c * get(n0, b));
+}
+
+// The ray in the primitive's leaf space: TranslatedInstance (Hitables.cpp:166) then, for a rect
+// with a live rotation, RotZ, RotY, RotX (outermost first; SimpleObject.cpp:173-181).
+// A rotation chain whose three angles are 0 is skipped: 1*x + (+-0)*y == x for finite input, so
+// only the sign of a zero can differ.
+template <class P>
+__device__ __forceinline__ void to_leaf_space(const P &pr, uint32_t info, f3 &o, f3 &d)
+{
+    o = o - mk(pr.off[0], pr.off[1], pr.off[2]);
+    if (PI_ROT(info)) {
+        rot_in(o, d, 2, pr.rot[4], pr.rot[5]);
+        rot_in(o, d, 1, pr.rot[2], pr.rot[3]);
+        rot_in(o, d, 0, pr.rot[0], pr.rot[1]);
+    }
+}
+
+// t of the closest accepted intersection of one primitive, or false.  Sphere: Hitables.cpp:20-43
+// (centre 0, SimpleObject.cpp:136); rect: Hitables.cpp:95-100.  a_dd = dot(dir,dir) is passed in
+// because it does not depend on the primitive when no rotation is live.
+template <class P>
+__device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, float t_max, float &t_out)
+{
+    uint32_t info = pr.info;
+    to_leaf_space(pr, info, o, d);
+    if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
+        float a = dot(d, d);
+        float b = 2.0f * dot(d, o);
+        float c = dot(o, o) - pr.g[2];
+        float disc = b * b - 4 * a * c;
+        if (disc > 0) {
+            float sq = __builtin_sqrtf(disc);
+            float t = (-b - sq) / (2.0f * a);
+            if (t <= t_max && t >= t_min) { t_out = t; return true; }
+            t = (-b + sq) / (2.0f * a);
+            if (t <= t_max && t >= t_min) { t_out = t; return true; }
+        }
+        return false;
+    }
+    uint32_t aA = PI_AAX(info), bA = PI_BAX(info), cA = PI_CAX(info);
+    float t = (pr.g[4] - get(o, cA)) / get(d, cA);
+    if (t <= t_max && t >= t_min) {
+        float a = get(o, aA) + t * get(d, aA);
+        float b = get(o, bA) + t * get(d, bA);
+        if (a >= pr.g[0] && a <= pr.g[1] && b >= pr.g[2] && b <= pr.g[3]) { t_out = t; return true; }
+    }
+    return false;
+}
+
+// The HitRecord of an accepted intersection (Hitables.cpp:35-39,102-109, then the instance chain
+// on the way out: :253-260 per rotation, :169 translate).  Recomputed from (prim, t): every step
+// is a deterministic function of the same inputs, so the bits equal the reference's in-place
+// record.  with_uv additionally evaluates CalculateUV (Hitables.cpp:62-78) / the rect's u,v.
+template <class P>
+__device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 d, float t, bool with_uv, Hit &h)
+{
+    uint32_t info = pr.info;
+    to_leaf_space(pr, info, o, d);
+    h.t = t; h.mat = (int32_t)pr.mat; h.prim = prim; h.u = 0.0f; h.v = 0.0f;
+    h.pos = ray_at(o, d, t);
+    if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
+        h.nrm = scale(h.pos, pr.g[1]);                         // (pos - 0) / r == * (1.f/r), Vec3.h:85-88
+        if (with_uv) {
+            f3 p = normalize(h.pos);
+            float theta = atan2f(p.z, p.x);
+            float phi = asinf(p.y);
+            const float PI = 3.14159265358979323846f;
+            h.u = 1.0f - (theta + PI) / (2.0f * PI);
+            h.v = (phi + PI / 2.0f) / PI;
+        }
+    } else {
+        uint32_t aA = PI_AAX(info), bA = PI_BAX(info), cA = PI_CAX(info);
+        if (with_uv) {
+            float a = get(o, aA) + t * get(d, aA);
+            float b = get(o, bA) + t * get(d, bA);
+            h.u = (a - pr.g[0]) / (pr.g[1] - pr.g[0]);
+            h.v = (b - pr.g[2]) / (pr.g[3] - pr.g[2]);
+        }
+        h.nrm = mk(0.0f, 0.0f, 0.0f);
+        set(h.nrm, cA, PI_REV(info) ? -1.0f : 1.0f);
+        if (PI_ROT(info)) {
+            rot_out(h.pos, h.nrm, 0, pr.rot[0], pr.rot[1]);
+            rot_out(h.pos, h.nrm, 1, pr.rot[2], pr.rot[3]);
+            rot_out(h.pos, h.nrm, 2, pr.rot[4], pr.rot[5]);
+        }
+    }
+    h.pos = h.pos + mk(pr.off[0], pr.off[1], pr.off[2]);
+}
+
+// ----------------------------------------------------------------------------- Optics.h
+__device__ __forceinline__ f3 reflect(f3 v, f3 n) { return v - scale(n, 2 * dot(v, n)); }            // Optics.h:8-12
+__device__ __forceinline__ bool refract(f3 v, f3 n, float ni_over_nt, f3 &refracted)                 // Optics.h:14-23
+{
+    float dt = dot(v, n);
+    float disc = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    bool ret = disc > 0;
+    if (ret) refracted = scale(v - scale(n, dt), ni_over_nt) - scale(n, __builtin_sqrtf(disc));
+    return ret;
+}
+// Optics.h:27-32; pow(float,int) -> x^5 in double rounded once, as the oracle defines it.
+__device__ __forceinline__ float pow5f(float x) { double d = x, d2 = d * d, d4 = d2 * d2; return (float)(d4 * d); }
+__device__ __forceinline__ float schlick(float cosine, float ref_idx)
+{
+    float r0 = (1 - ref_idx) / (1 + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1 - r0) * pow5f(1 - cosine);
+}
+
+// ----------------------------------------------------------------------------- Materials.cpp
+struct Scat { bool alive; f3 atten, dir, emitted; };
+
+template <class M, class G>
+__device__ __forceinline__ void scatter(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, G &g, Scat &o)
+{
+    o.emitted = mk(0.0f, 0.0f, 0.0f);                                   // HomemadeRayTracer.cpp:173
+    o.atten = mk(0.0f, 0.0f, 0.0f);
+    o.dir = mk(0.0f, 0.0f, 0.0f);
+    uint32_t kind = m.kind;
+    if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
+        o.alive = dot(dir_in, nrm) < 0;
+        o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        if (G::lazy && !o.alive) return;
+        f3 target = (pos + nrm) + in_unit_sphere(g);
+        o.dir = target - pos;
+    } else if (kind == MIRT_MAT_METAL) {                                // Materials.cpp:99-106
+        f3 refl = reflect(normalize(dir_in), nrm);
+        o.dir = refl + scale(in_unit_sphere(g), m.fuzz);
+        o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        o.alive = dot(o.dir, nrm) > 0;
+    } else if (kind == MIRT_MAT_DIELECTRIC) {                           // Materials.cpp:172-217
+        float ior = m.ior;
+        f3 uv = normalize(dir_in), outward, refracted = mk(0.0f, 0.0f, 0.0f);
+        float ni_over_nt, cosine, reflect_prob;
+        o.atten = mk(1.0f, 1.0f, 1.0f);
+        float dn = dot(uv, nrm);
+        if (dn > 0) { outward = neg(nrm); ni_over_nt = ior; cosine = ior * dn; }
+        else { outward = nrm; ni_over_nt = 1.0f / ior; cosine = -dn; }
+        if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ior);
+        else reflect_prob = 1.0f;
+        if (scatter_unorm(g) < reflect_prob) o.dir = reflect(uv, nrm);
+        else o.dir = refracted;
+        o.alive = true;
+    } else {                                                            // DiffuseLight, Materials.cpp:260-264
+        o.emitted = mk(m.emit[0], m.emit[1], m.emit[2]);
+        o.alive = false;
+    }
+}
+
+// ----------------------------------------------------------------------------- SimpleCamera.cpp:55-60
+__device__ __forceinline__ void camera_ray(const mirt_camera &c, float u, float v, f3 disk, f3 &org, f3 &dir)
+{
+    f3 rd = scale(disk, c.lens_radius);
+    f3 cu = mk(c.u[0], c.u[1], c.u[2]), cv = mk(c.v[0], c.v[1], c.v[2]);
+    f3 offset = scale(cu, rd.x) + scale(cv, rd.y);
+    f3 origin = mk(c.origin[0], c.origin[1], c.origin[2]);
+    f3 d = mk(c.top_left[0], c.top_left[1], c.top_left[2]) + scale(mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]), u);
+    d = d + scale(mk(c.vertical[0], c.vertical[1], c.vertical[2]), v);
+    d = d - origin;
+    d = d - offset;
+    org = origin + offset;
+    dir = d;
+}
+
+} // namespace mirt

@@ -1,0 +1,410 @@
+// rt_kernels.h -- the gfx950 kernels of the wavefront path tracer.
+//
+// Pipeline of one batch (a run of pixels x a run of samples, one path per (pixel, sample)):
+//
+//   k_bounce<FIRST>   depth 0: ray generation fused with the first extend+shade
+//   k_bounce          depth 1..max_depth: extend (closest hit) + shade (scatter) of the live paths
+//   k_accumulate      ordered per-pixel sum of the batch's per-sample radiance
+//   k_resolve         mean, sqrt gamma, clamp, RGBA8  (once per image)
+//
+// A path contributes radiance exactly once, at the vertex where it ends (emission is non-zero
+// only on DiffuseLight, which never scatters, Materials.cpp:260-264, and on a miss,
+// HomemadeRayTracer.cpp:186), so each path writes one float4 into rad[] when it terminates and
+// k_accumulate adds the samples of a pixel in sample order -- the same order as the reference's
+// `col += Sample(r, 0)` loop (HomemadeRayTracer.cpp:126-133).  No float atomics, no run-to-run
+// variation.
+//
+// Live paths are kept dense: each bounce reads queue `in` (SoA: origin, direction, throughput,
+// pixel, sample; lane i reads element base+i of every array, fully coalesced) and the survivors
+// are appended to queue `out` with a wave ballot + prefix popcount, one atomic per workgroup.
+#pragma once
+#include "rt_device.h"
+
+namespace mirt {
+
+#define MIRT_BLOCK 256
+
+struct PathQ {
+    float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
+    uint32_t *pix, *smp;
+};
+
+struct SceneDev {
+    const PrimRec *prims;  uint32_t n_prims;
+    const NodeRec *nodes;  uint32_t n_nodes;
+    const uint2   *objs;   uint32_t n_objects;   // (first, count)
+    const MatRec  *mats;   uint32_t n_mats;
+    int32_t root;
+    float   ambient[3];
+    // dynamic-LDS plan (in records): [prims][nodes][mats][stack]
+    uint32_t lds_prims, lds_nodes, lds_mats, stack_depth;
+};
+
+struct BounceArgs {
+    PathQ in, out;
+    const uint32_t *count_in;
+    uint32_t *count_out;
+    uint32_t n_first;
+    float4 *rad;
+    SceneDev sc;
+    mirt_camera cam;
+    uint32_t width, height, pix0, npix, spp0;
+    uint32_t depth, max_depth, flags, k0, k1;
+};
+
+// ---------------------------------------------------------------------------------- LDS staging
+struct LdsView {
+    PrimRec *prims; NodeRec *nodes; MatRec *mats; int32_t *stack;
+};
+__device__ __forceinline__ LdsView lds_view(const SceneDev &sc, unsigned char *base)
+{
+    LdsView v;
+    v.prims = (PrimRec *)base;
+    v.nodes = (NodeRec *)(base + sizeof(PrimRec) * sc.lds_prims);
+    v.mats = (MatRec *)((unsigned char *)v.nodes + sizeof(NodeRec) * sc.lds_nodes);
+    v.stack = (int32_t *)((unsigned char *)v.mats + sizeof(MatRec) * sc.lds_mats);
+    return v;
+}
+__device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t bytes)
+{
+    const uint4 *s = (const uint4 *)src; uint4 *d = (uint4 *)dst;
+    for (uint32_t i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
+}
+__device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
+{
+    lds_copy16(v.prims, sc.prims, sizeof(PrimRec) * sc.lds_prims);
+    lds_copy16(v.nodes, sc.nodes, sizeof(NodeRec) * sc.lds_nodes);
+    lds_copy16(v.mats, sc.mats, sizeof(MatRec) * sc.lds_mats);
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------- closest hit
+// List: Hitables.cpp:130-142 semantics over every object in order (= every primitive in order):
+// t_max shrinks on each accepted hit, `<=` lets a later primitive win a tie.  All lanes walk the
+// same primitive, so the records are wave-uniform LDS broadcasts.
+template <bool PLDS>
+__device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
+                                                float t_min, float &t_max)
+{
+    int32_t best = -1;
+    const PrimRec *P = PLDS ? v.prims : sc.prims;
+    for (uint32_t p = 0; p < sc.n_prims; ++p) {
+        float t;
+        if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+    }
+    return best;
+}
+
+// BVH: SimpleObjectBVHNode::Hit (SimpleObject.cpp:389-406) as an explicit depth-first walk in the
+// recursion's order: box test with the *current* t_max when the node is reached (AABB.cpp:5-21),
+// left subtree completely, then right.  The pending right children live on a per-lane stack in
+// LDS ([level][lane] so a level is one conflict-free row); nodes with index < lds_nodes (the top
+// levels, nodes are numbered breadth-first at upload) are read from LDS, deeper ones from HBM as
+// one 32-byte record per lane.
+template <bool PLDS>
+__device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
+                                               float t_min, float &t_max)
+{
+    int32_t best = -1;
+    int32_t *stk = v.stack + threadIdx.x;
+    uint32_t sp = 0;
+    int32_t cur = sc.root;
+    const PrimRec *P = PLDS ? v.prims : sc.prims;
+    for (;;) {
+        if (cur >= 0) {
+            NodeRec n;
+            if ((uint32_t)cur < sc.lds_nodes) n = v.nodes[cur];
+            else {
+                const float4 *g = (const float4 *)(sc.nodes + cur);
+                float4 a = g[0], b = g[1];
+                n.mn[0] = a.x; n.mn[1] = a.y; n.mn[2] = a.z; n.left = __float_as_int(a.w);
+                n.mx[0] = b.x; n.mx[1] = b.y; n.mx[2] = b.z; n.right = __float_as_int(b.w);
+            }
+            if (aabb_hit(n.mn, n.mx, o, d, t_min, t_max)) {
+                if (n.right != MIRT_CHILD_NONE && sp < sc.stack_depth) { stk[sp * MIRT_BLOCK] = n.right; ++sp; }
+                cur = n.left;
+                continue;
+            }
+        } else if (cur != MIRT_CHILD_NONE) {
+            uint2 ob = sc.objs[~cur];                       // Object::Hit, SimpleObject.cpp:73-83
+            for (uint32_t i = 0; i < ob.y; ++i) {
+                float t;
+                uint32_t p = ob.x + i;
+                if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stk[sp * MIRT_BLOCK];
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------- ray generation
+// HomemadeRayTracer.cpp:114-131 + SimpleCamera.cpp:55-60 + Randomizer.h:50-58
+__device__ __forceinline__ void generate_ray(const BounceArgs &a, uint32_t pixel, uint32_t sample, f3 &o, f3 &d)
+{
+    uint32_t i = pixel % a.width, j = pixel / a.width;
+    PhiloxKeyed g; g.pixel = pixel; g.sample = sample; g.stage = 0; g.k0 = a.k0; g.k1 = a.k1;
+    uint32_t r[4]; g.block(0, r);
+    float u, v;
+    if (a.flags & MIRT_FLAG_ONE_SPP) {
+        u = (float)i / (float)a.width;
+        v = (float)j / (float)a.height;
+    } else {
+        u = ((float)i + map_unorm(r[0])) / (float)a.width;
+        v = ((float)j + map_unorm(r[1])) / (float)a.height;
+    }
+    // RandomInUnitDisk: iteration 0 = block 0 lanes 2,3; iterations 2k-1, 2k = block k
+    f3 p = mk(map_pm1(r[2]), map_pm1(r[3]), 0.0f);
+    for (uint32_t it = 1; it < MIRT_REJECT_CAP && dot(p, p) >= 1.0f; ++it) {
+        uint32_t k = 2u + 2u * it;
+        if ((k & 3u) == 0u) g.block(k >> 2, r);
+        p = mk(map_pm1(r[k & 3u]), map_pm1(r[(k & 3u) + 1u]), 0.0f);
+    }
+    camera_ray(a.cam, u, v, p, o, d);
+}
+
+// ---------------------------------------------------------------------------------- the bounce kernel
+template <bool FIRST, int ACCEL /*0 list, 1 bvh*/, bool PLDS>
+__global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint32_t s_wcnt[MIRT_BLOCK / 64];
+    __shared__ uint32_t s_base;
+
+    const uint32_t n_in = FIRST ? a.n_first : *a.count_in;
+    if (blockIdx.x * MIRT_BLOCK >= n_in) return;
+    const LdsView lv = lds_view(a.sc, smem);
+    lds_stage(a.sc, lv);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+
+    for (uint32_t base = blockIdx.x * MIRT_BLOCK; base < n_in; base += gridDim.x * MIRT_BLOCK) {
+        const uint32_t idx = base + threadIdx.x;
+        const bool active = idx < n_in;
+        f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
+        uint32_t pixel = 0, sample = 0;
+        if (active) {
+            if (FIRST) {
+                uint32_t sl = idx / a.npix, pl = idx - sl * a.npix;
+                pixel = a.pix0 + pl; sample = a.spp0 + sl;
+                generate_ray(a, pixel, sample, o, d);
+            } else {
+                o = mk(a.in.ox[idx], a.in.oy[idx], a.in.oz[idx]);
+                d = mk(a.in.dx[idx], a.in.dy[idx], a.in.dz[idx]);
+                thr = mk(a.in.tr[idx], a.in.tg[idx], a.in.tb[idx]);
+                pixel = a.in.pix[idx]; sample = a.in.smp[idx];
+            }
+        }
+        bool alive = false;
+        f3 no = o, nd = d;
+        if (active) {
+            // -------- extend: HomemadeRayTracer.cpp:160-162
+            float t_max = 3.402823466e+38f;   // FLT_MAX
+            const float t_min = 0.001f;
+            int32_t best = ACCEL ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max)
+                                 : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max);
+            // -------- shade: HomemadeRayTracer.cpp:163-187, forward (throughput) order
+            f3 radiance;
+            if (best < 0) {
+                radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]);
+            } else {
+                Hit h;
+                const PrimRec *P = PLDS ? lv.prims : a.sc.prims;
+                prim_record(P[best], best, o, d, t_max, false, h);
+                if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {
+                    radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f);
+                } else if (!(a.depth < a.max_depth)) {
+                    radiance = mk(0.0f, 0.0f, 0.0f);          // Scatter not called: emitted stays zero (:173-174)
+                } else {
+                    const MatRec *M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
+                    PhiloxKeyed g; g.pixel = pixel; g.sample = sample; g.stage = 1u + a.depth; g.k0 = a.k0; g.k1 = a.k1;
+                    Scat s;
+                    scatter(*M, d, h.pos, h.nrm, g, s);
+                    if (s.alive) { alive = true; no = h.pos; nd = s.dir; thr = thr * s.atten; }
+                    else radiance = thr * s.emitted;
+                }
+            }
+            if (!alive) {
+                uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
+                a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            }
+        }
+        // -------- compaction: wave ballot + prefix popcount, one atomic per workgroup
+        const unsigned long long m = __ballot(alive);
+        const uint32_t wcnt = (uint32_t)__popcll(m);
+        const uint32_t wpre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcnt[wave] = wcnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < MIRT_BLOCK / 64; ++w) tot += s_wcnt[w];
+            s_base = tot ? atomicAdd(a.count_out, tot) : 0u;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t pos = s_base + wpre;
+            for (uint32_t w = 0; w < wave; ++w) pos += s_wcnt[w];
+            a.out.ox[pos] = no.x; a.out.oy[pos] = no.y; a.out.oz[pos] = no.z;
+            a.out.dx[pos] = nd.x; a.out.dy[pos] = nd.y; a.out.dz[pos] = nd.z;
+            a.out.tr[pos] = thr.x; a.out.tg[pos] = thr.y; a.out.tb[pos] = thr.z;
+            a.out.pix[pos] = pixel; a.out.smp[pos] = sample;
+        }
+        __syncthreads();   // s_wcnt / s_base are rewritten by the next iteration
+    }
+}
+
+// ---------------------------------------------------------------------------------- accumulate
+// HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
+__global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const float4 *__restrict__ rad, float *__restrict__ sum,
+                                                           uint32_t pix0, uint32_t npix, uint32_t nsamp, uint32_t overwrite)
+{
+    uint32_t pl = blockIdx.x * MIRT_BLOCK + threadIdx.x;
+    if (pl >= npix) return;
+    float *s = sum + 3 * (size_t)(pix0 + pl);
+    f3 acc = overwrite ? mk(0.0f, 0.0f, 0.0f) : mk(s[0], s[1], s[2]);
+    if (overwrite) { float4 r = rad[pl]; acc = mk(r.x, r.y, r.z); }
+    else for (uint32_t k = 0; k < nsamp; ++k) { float4 r = rad[(size_t)k * npix + pl]; acc = acc + mk(r.x, r.y, r.z); }
+    s[0] = acc.x; s[1] = acc.y; s[2] = acc.z;
+}
+
+// ---------------------------------------------------------------------------------- resolve
+// HomemadeRayTracer.cpp:134-138 and OutputImage.cpp:76-83.
+__device__ __forceinline__ float clamp01(float v)
+{
+    float m = (0.0f > v) ? 0.0f : v;        // _mm_max_ps(lo, v)
+    return (1.0f < m) ? 1.0f : m;           // _mm_min_ps(hi, m)
+}
+__device__ __forceinline__ uint32_t to_byte(float c)
+{
+    float s = c * 255.0f;
+    if (!(s == s)) return 0u;               // NaN -> cvttss2si gives 0x80000000, & 0xFF = 0
+    return ((uint32_t)s) & 0xFFu;
+}
+__global__ void __launch_bounds__(MIRT_BLOCK) k_resolve(const float *__restrict__ sum, uint32_t npix, uint32_t spp_total,
+                                                        uint32_t flags, float *__restrict__ pixels, uint32_t *__restrict__ rgba8)
+{
+    uint32_t p = blockIdx.x * MIRT_BLOCK + threadIdx.x;
+    if (p >= npix) return;
+    f3 col = mk(sum[3 * (size_t)p], sum[3 * (size_t)p + 1], sum[3 * (size_t)p + 2]);
+    if (!(flags & MIRT_FLAG_ONE_SPP)) col = scale(col, 1.f / (float)spp_total);      // Vec3.h:30
+    col = mk(__builtin_sqrtf(col.x), __builtin_sqrtf(col.y), __builtin_sqrtf(col.z));
+    if (pixels) { pixels[3 * (size_t)p] = col.x; pixels[3 * (size_t)p + 1] = col.y; pixels[3 * (size_t)p + 2] = col.z; }
+    if (rgba8) rgba8[p] = to_byte(clamp01(col.x)) | (to_byte(clamp01(col.y)) << 8) | (to_byte(clamp01(col.z)) << 16) | 0xFF000000u;
+}
+
+// ---------------------------------------------------------------------------------- function-level hooks
+__device__ __forceinline__ void store_hit(mirt_hit *o, const Hit &h, bool hit)
+{
+    if (!hit) { mirt_hit z = {}; z.mat = -1; z.prim = -1; *o = z; return; }
+    o->t = h.t; o->pos[0] = h.pos.x; o->pos[1] = h.pos.y; o->pos[2] = h.pos.z;
+    o->nrm[0] = h.nrm.x; o->nrm[1] = h.nrm.y; o->nrm[2] = h.nrm.z; o->u = h.u; o->v = h.v;
+    o->mat = h.mat; o->prim = h.prim;
+}
+
+__global__ void k_aabb_batch(const float *bmin, const float *bmax, uint32_t nbox, const float *org, const float *dir,
+                             uint32_t nray, float t_min, float t_max, uint8_t *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nray) return;
+    f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    for (uint32_t b = 0; b < nbox; ++b) {
+        float mn[3] = { bmin[3 * b], bmin[3 * b + 1], bmin[3 * b + 2] }, mx[3] = { bmax[3 * b], bmax[3 * b + 1], bmax[3 * b + 2] };
+        out[(size_t)i * nbox + b] = aabb_hit(mn, mx, o, d, t_min, t_max) ? 1 : 0;
+    }
+}
+
+__global__ void k_prim_hit_batch(SceneDev sc, uint32_t prim, const float *org, const float *dir, uint32_t nray,
+                                 float t_min, float t_max, mirt_hit *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nray) return;
+    f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    float t; Hit h;
+    bool hit = prim_t(sc.prims[prim], o, d, t_min, t_max, t);
+    if (hit) prim_record(sc.prims[prim], (int32_t)prim, o, d, t, true, h);
+    store_hit(out + i, h, hit);
+}
+
+template <int ACCEL, bool PLDS>
+__global__ void __launch_bounds__(MIRT_BLOCK) k_world_hit_batch(SceneDev sc, const float *org, const float *dir, uint32_t nray,
+                                                                float t_min, float t_max, mirt_hit *out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LdsView lv = lds_view(sc, smem);
+    lds_stage(sc, lv);
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nray) return;
+    f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+    float tm = t_max;
+    int32_t best = ACCEL ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm);
+    Hit h;
+    const PrimRec *P = PLDS ? lv.prims : sc.prims;
+    if (best >= 0) prim_record(P[best], best, o, d, tm, true, h);
+    store_hit(out + i, h, best >= 0);
+}
+
+__global__ void k_scatter_batch(SceneDev sc, const mirt_hit *hits, const float *dir_in, uint32_t n, const uint32_t *draws,
+                                uint32_t dpr, uint8_t *alive, float *atten, float *oorg, float *odir, float *oemit, uint32_t *consumed)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mirt_hit hh = hits[i];
+    StreamDraws g; g.p = draws + (size_t)i * dpr; g.n = dpr; g.pos = 0;
+    f3 pos = mk(hh.pos[0], hh.pos[1], hh.pos[2]), nrm = mk(hh.nrm[0], hh.nrm[1], hh.nrm[2]);
+    f3 din = mk(dir_in[3 * i], dir_in[3 * i + 1], dir_in[3 * i + 2]);
+    Scat s; s.alive = false;
+    scatter(sc.mats[hh.mat], din, pos, nrm, g, s);
+    alive[i] = s.alive ? 1 : 0;
+    atten[3 * i] = s.atten.x; atten[3 * i + 1] = s.atten.y; atten[3 * i + 2] = s.atten.z;
+    oorg[3 * i] = pos.x; oorg[3 * i + 1] = pos.y; oorg[3 * i + 2] = pos.z;
+    odir[3 * i] = s.dir.x; odir[3 * i + 1] = s.dir.y; odir[3 * i + 2] = s.dir.z;
+    oemit[3 * i] = s.emitted.x; oemit[3 * i + 1] = s.emitted.y; oemit[3 * i + 2] = s.emitted.z;
+    if (consumed) consumed[i] = g.pos;
+}
+
+__global__ void k_camera_rays(mirt_camera cam, const float *uv, uint32_t n, const uint32_t *draws, uint32_t dpr,
+                              float *oorg, float *odir, uint32_t *consumed)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StreamDraws g; g.p = draws + (size_t)i * dpr; g.n = dpr; g.pos = 0;
+    f3 p = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t it = 0; it < MIRT_REJECT_CAP; ++it) {                // Randomizer.h:50-58
+        float x = map_pm1(g.next()), y = map_pm1(g.next());
+        p = mk(x, y, 0.0f);
+        if (!(dot(p, p) >= 1.0f)) break;
+    }
+    f3 o, d;
+    camera_ray(cam, uv[2 * i], uv[2 * i + 1], p, o, d);
+    oorg[3 * i] = o.x; oorg[3 * i + 1] = o.y; oorg[3 * i + 2] = o.z;
+    odir[3 * i] = d.x; odir[3 * i + 1] = d.y; odir[3 * i + 2] = d.z;
+    if (consumed) consumed[i] = g.pos;
+}
+
+__global__ void k_philox_batch(const uint32_t *ctr, uint32_t n, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r[4];
+    philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, r);
+    out[4 * i] = r[0]; out[4 * i + 1] = r[1]; out[4 * i + 2] = r[2]; out[4 * i + 3] = r[3];
+}
+
+// arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a)
+__global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n, float *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y ? y[i] : 0.0f, r;
+    switch (op) {
+    case 0: r = a / b; break;
+    case 1: r = __builtin_sqrtf(a); break;
+    case 2: r = pow5f(a); break;
+    case 3: r = map_unorm(__float_as_uint(a)); break;
+    default: r = map_pm1(__float_as_uint(a)); break;
+    }
+    out[i] = r;
+}
+
+} // namespace mirt

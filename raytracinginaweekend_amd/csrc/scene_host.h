@@ -1,0 +1,184 @@
+// scene_host.h -- host-side scene preparation of libmirt: validation of a mirt_scene, object
+// bounding boxes, the library's own BVH builder (used when the caller passes no tree), breadth-
+// first renumbering and packing into the device records of rt_device.h.
+//
+// Bounding boxes restate IHitable::BoundingBox (Hitables.cpp:56-60 sphere, :117-128 rect,
+// :152-161 combo, :175-180 translate, :208-238 rotate) and CombineAABB (AABB.h:19-34).
+// File:line citations are relative to /root/reference/RayTracer/RayTracer/.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/mirt.h"
+
+namespace mirt { namespace host {
+
+struct Box { float mn[3], mx[3]; };
+
+inline Box combine(const Box &a, const Box &b)                        // AABB.h:19-34
+{
+    Box r;
+    for (int i = 0; i < 3; ++i) { r.mn[i] = (a.mn[i] < b.mn[i]) ? a.mn[i] : b.mn[i]; r.mx[i] = (a.mx[i] > b.mx[i]) ? a.mx[i] : b.mx[i]; }
+    return r;
+}
+inline Box rect_box(const mirt_scene &s, uint32_t p)                  // Hitables.cpp:117-128
+{
+    uint32_t ax = s.prim_axes[p]; const float *g = s.prim_geom + 5 * (size_t)p;
+    uint32_t a = ax & 3, b = (ax >> 2) & 3, c = (ax >> 4) & 3;
+    Box r = {};
+    r.mn[a] = g[0]; r.mx[a] = g[1]; r.mn[b] = g[2]; r.mx[b] = g[3];
+    r.mn[c] = g[4] - 0.0001f; r.mx[c] = g[4] + 0.0001f;
+    return r;
+}
+inline Box rot_box(const Box &in, uint32_t axis, float sn, float cs)  // Hitables.cpp:188-238
+{
+    uint32_t aA, bA; float OP;
+    if (axis == 0) { aA = 1; bA = 2; OP = -1.0f; } else if (axis == 1) { aA = 0; bA = 2; OP = 1.0f; } else { aA = 0; bA = 1; OP = -1.0f; }
+    Box r; for (int i = 0; i < 3; ++i) { r.mn[i] = FLT_MAX; r.mx[i] = -FLT_MAX; }
+    for (uint32_t i = 0; i < 2; ++i) for (uint32_t j = 0; j < 2; ++j) for (uint32_t k = 0; k < 2; ++k) {
+        float a = i * in.mx[aA] + (1 - i) * in.mn[aA];
+        float b = j * in.mx[bA] + (1 - j) * in.mn[bA];
+        float c = k * in.mx[axis] + (1 - k) * in.mn[axis];
+        float t[3]; t[aA] = cs * a + OP * sn * b; t[bA] = -OP * sn * a + cs * b; t[axis] = c;
+        for (int x = 0; x < 3; ++x) { if (t[x] > r.mx[x]) r.mx[x] = t[x]; if (t[x] < r.mn[x]) r.mn[x] = t[x]; }
+    }
+    return r;
+}
+inline Box object_box(const mirt_scene &s, uint32_t obj)
+{
+    uint32_t first = s.obj_first[obj], cnt = s.obj_count[obj];
+    Box b;
+    if (s.prim_kind[first] == MIRT_PRIM_SPHERE) {                      // Hitables.cpp:56-60
+        float r = s.prim_geom[5 * (size_t)first];
+        for (int i = 0; i < 3; ++i) { b.mn[i] = 0.0f - r; b.mx[i] = r; }
+    } else {
+        b = rect_box(s, first);
+        for (uint32_t i = 1; i < cnt; ++i) b = combine(rect_box(s, first + i), b);   // Hitables.cpp:152-161
+        if ((s.prim_axes[first] >> 7) & 1) {
+            const float *q = s.prim_rot + 6 * (size_t)first;
+            b = rot_box(b, 0, q[0], q[1]); b = rot_box(b, 1, q[2], q[3]); b = rot_box(b, 2, q[4], q[5]);
+        }
+    }
+    for (int i = 0; i < 3; ++i) { b.mn[i] = b.mn[i] + s.prim_off[3 * (size_t)first + i]; b.mx[i] = b.mx[i] + s.prim_off[3 * (size_t)first + i]; }  // :175-180
+    return b;
+}
+
+struct Tree {
+    std::vector<Box> box; std::vector<int32_t> left, right; int32_t root = MIRT_CHILD_NONE;
+    uint32_t depth = 0;
+};
+
+// The library's own builder, O(N log N): median split (nth_element) of the object translations on
+// the widest axis of their extent; leaves shaped like the reference's (a node over one or two
+// objects, SimpleObject.cpp:308-322).  Any valid BVH gives the same closest hit.
+struct Builder {
+    const mirt_scene &s; const std::vector<Box> &ob; Tree &t;
+    int32_t build(uint32_t *o, size_t n)
+    {
+        int32_t me = (int32_t)t.box.size();
+        t.box.push_back(Box{}); t.left.push_back(MIRT_CHILD_NONE); t.right.push_back(MIRT_CHILD_NONE);
+        int32_t l, r;
+        if (n == 1) { l = ~(int32_t)o[0]; r = MIRT_CHILD_NONE; }
+        else if (n == 2) { l = ~(int32_t)o[0]; r = ~(int32_t)o[1]; }
+        else {
+            float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+            for (size_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) {
+                float c = s.prim_off[3 * (size_t)s.obj_first[o[i]] + a];
+                lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
+            }
+            int ax = 0; if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1; if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
+            size_t half = n / 2;
+            std::nth_element(o, o + half, o + n, [&](uint32_t x, uint32_t y) {
+                float cx = s.prim_off[3 * (size_t)s.obj_first[x] + ax], cy = s.prim_off[3 * (size_t)s.obj_first[y] + ax];
+                return cx < cy || (cx == cy && x < y);
+            });
+            l = build(o, half); r = build(o + half, n - half);
+        }
+        auto cb = [&](int32_t c) { return c < 0 ? ob[~c] : t.box[c]; };
+        t.box[me] = (r == MIRT_CHILD_NONE) ? cb(l) : combine(cb(l), cb(r));
+        t.left[me] = l; t.right[me] = r;
+        return me;
+    }
+};
+
+inline std::string validate(const mirt_scene &s)
+{
+    if (!s.n_prims || !s.n_objects || !s.n_mats) return "scene needs at least one primitive, object and material";
+    if (!s.prim_kind || !s.prim_off || !s.prim_geom || !s.prim_axes || !s.prim_rot || !s.prim_mat || !s.obj_first || !s.obj_count ||
+        !s.mat_kind || !s.mat_albedo || !s.mat_fuzz || !s.mat_ior || !s.mat_emit) return "null scene array";
+    uint32_t next = 0;
+    for (uint32_t o = 0; o < s.n_objects; ++o) {
+        if (s.obj_first[o] != next || s.obj_count[o] == 0) return "objects must be consecutive non-empty runs of primitives";
+        next += s.obj_count[o];
+        for (uint32_t i = 1; i < s.obj_count[o]; ++i)
+            if (s.prim_kind[s.obj_first[o] + i] != MIRT_PRIM_RECT || s.prim_kind[s.obj_first[o]] != MIRT_PRIM_RECT) return "a multi-primitive object must be rects (HitableCombo of a cube)";
+    }
+    if (next != s.n_prims) return "objects do not cover the primitives";
+    for (uint32_t p = 0; p < s.n_prims; ++p) {
+        if (s.prim_kind[p] > 1) return "bad primitive kind";
+        if (s.prim_mat[p] >= s.n_mats) return "material index out of range";
+        if (s.prim_kind[p] == MIRT_PRIM_RECT) {
+            uint32_t ax = s.prim_axes[p], a = ax & 3, b = (ax >> 2) & 3, c = (ax >> 4) & 3;
+            if (a > 2 || b > 2 || c > 2 || a == b || a == c || b == c) return "bad rect axes";
+        }
+    }
+    for (uint32_t m = 0; m < s.n_mats; ++m) if (s.mat_kind[m] > 3) return "bad material kind";
+    if (s.n_nodes) {
+        if (!s.node_min || !s.node_max || !s.node_left || !s.node_right) return "null BVH array";
+        if (s.root < 0 || (uint32_t)s.root >= s.n_nodes) return "BVH root out of range";
+    }
+    return "";
+}
+
+// Take the caller's tree (or build one), check it is a tree over valid indices, renumber the nodes
+// breadth-first (so "index < K" = the top levels, staged in LDS) and measure its depth.
+inline std::string prepare_tree(const mirt_scene &s, Tree &out)
+{
+    Tree t;
+    if (s.n_nodes) {
+        t.box.resize(s.n_nodes); t.left.assign(s.node_left, s.node_left + s.n_nodes); t.right.assign(s.node_right, s.node_right + s.n_nodes);
+        for (uint32_t i = 0; i < s.n_nodes; ++i) for (int a = 0; a < 3; ++a) { t.box[i].mn[a] = s.node_min[3 * (size_t)i + a]; t.box[i].mx[a] = s.node_max[3 * (size_t)i + a]; }
+        t.root = s.root;
+    } else {
+        std::vector<Box> ob(s.n_objects);
+        for (uint32_t o = 0; o < s.n_objects; ++o) ob[o] = object_box(s, o);
+        std::vector<uint32_t> idx(s.n_objects);
+        for (uint32_t o = 0; o < s.n_objects; ++o) idx[o] = o;
+        Builder b{ s, ob, t };
+        t.root = b.build(idx.data(), idx.size());
+    }
+    // BFS renumber + validation
+    size_t n = t.box.size();
+    std::vector<int32_t> order; order.reserve(n);
+    std::vector<int32_t> newid(n, -1);
+    std::vector<uint32_t> level;
+    order.push_back(t.root); newid[t.root] = 0; level.push_back(1);
+    uint32_t depth = 1;
+    for (size_t h = 0; h < order.size(); ++h) {
+        int32_t c = order[h];
+        int32_t ch[2] = { t.left[c], t.right[c] };
+        for (int k = 0; k < 2; ++k) {
+            int32_t x = ch[k];
+            if (x == MIRT_CHILD_NONE) continue;
+            if (x < 0) { if ((uint32_t)~x >= s.n_objects) return "BVH leaf object out of range"; continue; }
+            if ((size_t)x >= n) return "BVH child out of range";
+            if (newid[x] >= 0) return "BVH is not a tree (node reached twice)";
+            newid[x] = (int32_t)order.size(); order.push_back(x); level.push_back(level[h] + 1);
+            depth = std::max(depth, level[h] + 1);
+        }
+    }
+    out.box.resize(order.size()); out.left.resize(order.size()); out.right.resize(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        int32_t c = order[i];
+        out.box[i] = t.box[c];
+        out.left[i] = t.left[c] >= 0 ? newid[t.left[c]] : t.left[c];
+        out.right[i] = t.right[c] >= 0 ? newid[t.right[c]] : t.right[c];
+    }
+    out.root = 0; out.depth = depth;
+    return "";
+}
+
+}} // namespace mirt::host

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from tests import orc as _orc
+    return _orc
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    """One mirt context on cuda:0 for the whole session.  Fails loudly without the HIP library."""
+    from raytracinginaweekend_amd import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,193 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle, on the same seeded inputs.
+Bar: bit-exact (sign of zero excepted where rt_device.h skips identity rotations); sphere u,v use
+atan2f/asinf and are held to 2e-6 absolute."""
+import numpy as np
+import pytest
+
+from raytracinginaweekend_amd import capi, scene
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def test_arith_blocks(gpu, orc):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(size=20000) * 10.0 ** rng.uniform(-20, 20, 20000), [0.0, -0.0, 1e-40, 3e38, np.inf]]).astype(np.float32)
+    y = np.concatenate([rng.normal(size=20000) * 10.0 ** rng.uniform(-20, 20, 20000), [0.0, 1.0, 1e-40, 3e38, np.inf]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        H.assert_bits(gpu.arith_batch(0, x, y), (x / y).astype(np.float32), "div")
+        H.assert_bits(gpu.arith_batch(1, np.abs(x)), np.sqrt(np.abs(x)).astype(np.float32), "sqrt")
+        p = rng.uniform(-1.5, 1.5, 20000).astype(np.float32)
+        H.assert_bits(gpu.arith_batch(2, p), (p.astype(np.float64) ** 2 * p.astype(np.float64) ** 2 * p.astype(np.float64)).astype(np.float32), "pow5")
+    raw = np.concatenate([rng.integers(0, 2 ** 32, 50000, dtype=np.uint64), [0, 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 128, 2 ** 32 - 129]]).astype(np.uint32)
+    exp0 = np.array([orc.map_minmax(r, 0.0, 1.0) for r in raw[:4000]] + [orc.map_minmax(r, 0.0, 1.0) for r in raw[-6:]], np.float32)
+    exp1 = np.array([orc.map_minmax2(r, -1.0, 1.0) for r in raw[:4000]] + [orc.map_minmax2(r, -1.0, 1.0) for r in raw[-6:]], np.float32)
+    sel = np.concatenate([raw[:4000], raw[-6:]])
+    H.assert_bits(gpu.arith_batch(3, sel.view(np.float32)), exp0, "map_unorm")
+    H.assert_bits(gpu.arith_batch(4, sel.view(np.float32)), exp1, "map_pm1")
+    # all raw values against the closed forms, vectorised
+    d = raw.astype(np.float64)
+    H.assert_bits(gpu.arith_batch(3, raw.view(np.float32)), (d / 4294967296.0).astype(np.float32), "map_unorm/all")
+    H.assert_bits(gpu.arith_batch(4, raw.view(np.float32)), ((d / 4294967295.0) * 2.0 + -1.0).astype(np.float32), "map_pm1/all")
+
+
+def test_philox(gpu, orc):
+    rng = np.random.default_rng(2)
+    ctr = rng.integers(0, 2 ** 32, (512, 4), dtype=np.uint64).astype(np.uint32)
+    ctr[0] = 0; ctr[1] = 0xFFFFFFFF
+    key = np.array([0xA4093822, 0x299F31D0], np.uint32)
+    assert np.array_equal(gpu.philox_batch(ctr, key), orc.philox(ctr, key))
+    kat = gpu.philox_batch([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], key)
+    assert kat[0].tolist() == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]      # Random123 kat_vectors
+
+
+def test_aabb(gpu, orc):
+    rng = np.random.default_rng(3)
+    mn = rng.uniform(-2, 0, (32, 3)).astype(np.float32); mx = (mn + rng.uniform(0, 2, (32, 3))).astype(np.float32)
+    mx[0] = mn[0]                                                  # degenerate box
+    org, d = H.ray_batch(8192, 4)
+    for (t0, t1) in ((0.001, FLT_MAX), (0.001, 3.0), (1.5, 2.5)):
+        assert np.array_equal(gpu.aabb_hit_batch(mn, mx, org, d, t0, t1), orc.aabb_hit_batch(mn, mx, org, d, t0, t1))
+
+
+@pytest.mark.parametrize("world", ["cornell", "two_boxes", "spheres4"])
+def test_prim_hit(gpu, orc, world):
+    s, cam = {"cornell": scene.cornell_box, "two_boxes": scene.cornell_two_boxes,
+              "spheres4": lambda: scene.spheres_world(2.0, small_spheres=False)}[world]()
+    gpu.upload_scene(s)
+    for p in range(s.n_prims):
+        c = s.arrays()["prim_off"][p]
+        ext = 2.0 if s.kind[p] == capi.PRIM_RECT else 2.0 * s.geom[p][0]
+        org, d = H.ray_batch(4096, 100 + p, center=c, extent=min(ext, 50.0))
+        for (t0, t1) in ((0.001, FLT_MAX), (0.001, 4.0)):
+            g = gpu.prim_hit_batch(p, org, d, t0, t1); o = orc.prim_hit_batch(s, p, org, d, t0, t1)
+            assert (o["prim"] >= 0).sum() > 100
+            H.assert_hits_equal(g, o, f"{world} prim {p}", uv_tol=2e-6 if s.kind[p] == capi.PRIM_SPHERE else None)
+
+
+@pytest.mark.parametrize("world", ["cornell", "two_boxes", "spheres4", "spheres"])
+def test_world_hit(gpu, orc, world):
+    s, cam = {"cornell": scene.cornell_box, "two_boxes": scene.cornell_two_boxes,
+              "spheres4": lambda: scene.spheres_world(2.0, small_spheres=False),
+              "spheres": lambda: scene.spheres_world(1.5)}[world]()
+    draws = np.random.default_rng(7).integers(0, 2 ** 32, 4 * s.n_objects + 8, dtype=np.uint64).astype(np.uint32)
+    orc.bvh_build_reference(s, draws)                           # SimpleObjectBVHNode ctor, random axes
+    gpu.upload_scene(s)                                         # the device walks this very tree
+    ext = 2.0 if world != "spheres" and world != "spheres4" else 12.0
+    org, d = H.ray_batch(16384, 11, extent=ext)
+    for flags in (0, capi.FLAG_ACCEL_LIST):
+        g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags); o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
+        assert (o["prim"] >= 0).sum() > 1000
+        H.assert_hits_equal(g, o, f"{world} flags={flags}", uv_tol=2e-6)
+    # the library's own BVH (no tree passed): same closest hits as the list
+    s.nodes = None
+    gpu.upload_scene(s)
+    g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0); o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
+    same = g["prim"] == o["prim"]
+    assert same.mean() > 0.9999, f"own BVH disagrees with the list on {(~same).sum()} rays"
+    H.assert_bits(g["t"][same], o["t"][same], "own-bvh t")
+
+
+def test_scatter(gpu, orc):
+    s, cam = scene.cornell_box()
+    glass2 = s.dielectric(2.4); mirror = s.metal((0.7, 0.6, 0.5), 0.0); rough = s.metal((0.9, 0.9, 0.9), 5.0)
+    gpu.upload_scene(s)
+    rng = np.random.default_rng(5)
+    n = 4096 * len(s.mkind)
+    hits = np.zeros(n, capi.HIT_DTYPE)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hits["nrm"] = nrm.astype(np.float32); hits["pos"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+    hits["t"] = 1.0; hits["mat"] = np.arange(n) % len(s.mkind)
+    d = rng.normal(size=(n, 3)).astype(np.float32) * np.float32(3.0)
+    graze = rng.random(n) < 0.2                                  # near-tangent incidence: total internal reflection
+    d[graze] = (np.cross(nrm[graze], rng.normal(size=(graze.sum(), 3))) + 0.05 * nrm[graze] * rng.normal(size=(graze.sum(), 1))).astype(np.float32)
+    d[0] = 0.0                                                   # zero direction: normalize -> 0
+    draws = rng.integers(0, 2 ** 32, (n, 3 * 64), dtype=np.uint64).astype(np.uint32)
+    g = gpu.scatter_batch(hits, d, draws); o = orc.scatter_batch(s, hits, d, draws)
+    assert np.array_equal(g["alive"], o["alive"]) and np.array_equal(g["consumed"], o["consumed"])
+    for f in ("atten", "org", "dir", "emit"):
+        H.assert_bits(g[f], o[f], f"scatter.{f}")
+    assert o["consumed"].max() > 9 and 0 < o["alive"].mean() < 1
+
+
+def test_camera_rays(gpu, orc):
+    rng = np.random.default_rng(6)
+    for (s_cam, aspect) in ((scene.cornell_box, 1.0), (scene.spheres_world, 1.5), (lambda a: scene.spheres_world(a, small_spheres=False), 2.0)):
+        _, cam = s_cam(aspect)
+        gpu.set_camera(cam)
+        uv = rng.uniform(0, 1, (8192, 2)).astype(np.float32)
+        draws = rng.integers(0, 2 ** 32, (8192, 128), dtype=np.uint64).astype(np.uint32)
+        g = gpu.camera_rays(uv, draws); o = orc.camera_rays(cam, uv, draws)
+        assert np.array_equal(g["consumed"], o["consumed"]) and o["consumed"].max() >= 6
+        H.assert_bits(g["org"], o["org"], "camera.org"); H.assert_bits(g["dir"], o["dir"], "camera.dir")
+
+
+WORLDS = {
+    "cornell": (lambda: scene.cornell_box(1.0), 96, 96),
+    "two_boxes": (lambda: scene.cornell_two_boxes(1.0), 64, 64),
+    "spheres4": (lambda: scene.spheres_world(2.0, small_spheres=False), 200, 100),
+    "spheres": (lambda: scene.spheres_world(1.5), 120, 80),
+}
+
+
+@pytest.mark.parametrize("world", list(WORLDS))
+@pytest.mark.parametrize("accel", ["list", "bvh"])
+def test_image_exact(gpu, orc, world, accel):
+    """Same Philox keys, same arithmetic, ordered sample sum: the device image equals the oracle's
+    forward-order image bit for bit (floats and RGBA8), in 1-SPP, normal-display and multi-sample mode."""
+    mk, w, h = WORLDS[world]
+    s, cam = mk()
+    draws = np.random.default_rng(9).integers(0, 2 ** 32, 4 * s.n_objects + 8, dtype=np.uint64).astype(np.uint32)
+    orc.bvh_build_reference(s, draws)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    af = capi.FLAG_ACCEL_LIST if accel == "list" else 0
+    for (flags, spp) in ((capi.FLAG_ONE_SPP, 1), (capi.FLAG_NORMAL_DISPLAY | capi.FLAG_ONE_SPP, 1), (capi.FLAG_NORMAL_DISPLAY, 3), (0, 8)):
+        g = gpu.render(w, h, spp, 50, 0x5EED, flags | af)
+        osum, st = orc.trace(s, cam, w, h, spp, 50, 0x5EED, flags | af)
+        opx, orgba = orc.resolve(osum, spp, flags)
+        H.assert_bits(g["sum"], osum, f"{world}/{accel} flags={flags} sum")
+        H.assert_bits(g["pixels"], opx, f"{world}/{accel} flags={flags} pixels")
+        assert np.array_equal(g["rgba8"], orgba)
+        assert g["stats"].rays == st.rays, (g["stats"].rays, st.rays)
+
+
+def test_batching_and_ranges(gpu, orc):
+    """Small ray-queue capacity forces pixel tiles and sample tiles; sample ranges compose."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w = h = 64
+    ref = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
+    gpu.set_option("max_paths", 1500)                            # < w*h: pixel tiles of 1500, one sample each
+    a = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
+    gpu.set_option("max_paths", 3 * w * h + 17)                  # sample tiles of 3
+    b = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
+    gpu.set_option("max_paths", 32 << 20)
+    H.assert_bits(a["sum"], ref["sum"], "pixel tiles"); H.assert_bits(b["sum"], ref["sum"], "sample tiles")
+    osum, _ = orc.trace(s, cam, w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
+    H.assert_bits(ref["sum"], osum, "vs oracle")
+    # [0,5) then [5,12) accumulated by the oracle in two calls == one call (ordered sum)
+    part, _ = orc.trace(s, cam, w, h, 5, 50, 7, capi.FLAG_ACCEL_LIST)
+    part, _ = orc.trace(s, cam, w, h, 7, 50, 7, capi.FLAG_ACCEL_LIST, spp_begin=5, sum_rgb=part)
+    H.assert_bits(part, osum, "oracle ranges")
+
+
+def test_depth_limits(gpu, orc):
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    for md in (0, 1, 3):
+        g = gpu.render(48, 48, 4, md, 3, capi.FLAG_ACCEL_LIST)
+        osum, st = orc.trace(s, cam, 48, 48, 4, md, 3, capi.FLAG_ACCEL_LIST)
+        H.assert_bits(g["sum"], osum, f"max_depth={md}")
+
+
+def test_errors(gpu):
+    s, cam = scene.cornell_box(1.0)
+    bad = scene.FlatScene()
+    with pytest.raises(capi.MirtError):
+        gpu.upload_scene(bad)                                     # empty scene
+    s.pmat[0] = 99
+    s._arrays = None
+    with pytest.raises(capi.MirtError, match="material index"):
+        gpu.upload_scene(s)
