@@ -59,7 +59,8 @@ def test_prim_hit(gpu, orc, world):
     gpu.upload_scene(s)
     for p in range(s.n_prims):
         c = s.arrays()["prim_off"][p]
-        ext = 2.0 if s.kind[p] == capi.PRIM_RECT else 2.0 * s.geom[p][0]
+        gm = s.geom[p]
+        ext = 0.6 * max(gm[1] - gm[0], gm[3] - gm[2]) if s.kind[p] == capi.PRIM_RECT else 2.0 * gm[0]
         org, d = H.ray_batch(4096, 100 + p, center=c, extent=min(ext, 50.0))
         for (t0, t1) in ((0.001, FLT_MAX), (0.001, 4.0)):
             g = gpu.prim_hit_batch(p, org, d, t0, t1); o = orc.prim_hit_batch(s, p, org, d, t0, t1)
@@ -85,9 +86,10 @@ def test_world_hit(gpu, orc, world):
     s.nodes = None
     gpu.upload_scene(s)
     g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0); o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
-    same = g["prim"] == o["prim"]
-    assert same.mean() > 0.9999, f"own BVH disagrees with the list on {(~same).sum()} rays"
-    H.assert_bits(g["t"][same], o["t"][same], "own-bvh t")
+    # coplanar surfaces (a cube standing on the floor) tie in t and the later-tested primitive wins
+    # (Hitables.cpp:33,96 use <=), so the winner may differ with the visiting order; t may not
+    H.assert_bits(g["t"], o["t"], "own-bvh t")
+    assert np.array_equal(g["prim"] >= 0, o["prim"] >= 0)
 
 
 def test_scatter(gpu, orc):
