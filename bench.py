@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--max-depth", type=int, default=50)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--ppm", default="", help="write the last image as ASCII PPM (outside the timed region)")
     return ap.parse_args()
 
@@ -146,7 +146,10 @@ def main():
                "kernel": "k_bounce<depth>=1>", "launches": int(st.extend_launches),
                "avg_launch_ms": round(st.extend_ms / max(1, st.extend_launches), 4),
                "bytes_per_launch": round(ext_bytes / max(1, st.extend_launches), 1)}
-        roofline, other = (hbm, valu) if hbm["frac"] >= valu["frac"] else (valu, hbm)
+        # The bounce kernel is VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU ~ 80 % of SIMD cycles, HBM
+        # traffic = the algorithmic queue bytes), so the VALU roofline is the binding one; the HBM figure of
+        # the same launches is reported beside it.
+        roofline, other = valu, hbm
         out = {
             "metric": "Msamples/sec (whole node), Cornell box 3-ball 1024^2",
             "value": round(msamples, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

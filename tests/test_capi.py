@@ -1,0 +1,90 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/mirt.h declares,
+its structs have the layout the Python mirror assumes, and it fails loudly without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from raytracinginaweekend_amd import capi, scene, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mirt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mirt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"libmirt.so does not export {n}"
+    assert sorted(capi.EXPORTS) == names
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "mirt.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(mirt_scene), '
+                   'sizeof(mirt_camera), sizeof(mirt_hit), sizeof(mirt_render_params), sizeof(mirt_stats), offsetof(mirt_scene, ambient));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out == [C.sizeof(capi.SceneStruct), C.sizeof(capi.CameraStruct), capi.HIT_DTYPE.itemsize, C.sizeof(capi.RenderParams),
+                   C.sizeof(capi.Stats), capi.SceneStruct.ambient.offset]
+    # the oracle's orc_scene / orc_hit are layout-identical by construction: same check against its header
+    src2 = tmp_path / "sz2.c"
+    src2.write_text('#include <stdio.h>\n#include "rt_oracle.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(orc_scene), sizeof(orc_camera), '
+                    'sizeof(orc_hit), offsetof(orc_scene, ambient));return 0;}\n')
+    exe2 = tmp_path / "sz2"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "oracle"), str(src2), "-o", str(exe2)], check=True)
+    out2 = [int(x) for x in subprocess.run([str(exe2)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out2 == [out[0], out[1], out[2], out[5]]
+
+
+@pytest.mark.skipif(capi.load().mirt_device_count() > 0, reason="a GPU is present")
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    with pytest.raises(capi.MirtError, match="no HIP device"):
+        capi.Context(0)
+
+
+def test_product_code_never_touches_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracinginaweekend_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", ".c")) or f == "Makefile":
+                t = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"rt_oracle|libmirt_oracle|from tests|import tests|oracle/", t):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+def test_flat_scene_shapes():
+    s, cam = scene.cornell_box(1.0)
+    a = s.arrays()
+    assert s.n_prims == 9 and s.n_objects == 9 and a["prim_geom"].shape == (9, 5) and a["mat_albedo"].shape == (7, 3)
+    assert a["prim_axes"][0] == capi.axes_pack(0, 2, 1, 1, 1)                  # XZ light, reversed, rotation chain present
+    assert cam.lens_radius == 0.0
+    s2, cam2 = scene.cornell_two_boxes(1.0)
+    assert s2.n_prims == 18 and s2.n_objects == 8 and s2.obj_count[-1] == 6
+    s3, cam3 = scene.spheres_world(1.5)
+    assert 470 < s3.n_objects < 489 and abs(cam3.lens_radius - 0.05) < 1e-9     # SURVEY: ~486 spheres
+    s4, _ = scene.spheres_world(2.0, small_spheres=False)
+    assert s4.n_objects == 4
+    assert np.array_equal(scene.spheres_world(1.5)[0].arrays()["prim_off"], a3 := s3.arrays()["prim_off"]) and a3.shape[1] == 3   # reproducible
+
+
+def test_spp_ranges_tile_the_sample_space():
+    for world in (1, 2, 3, 4, 8):
+        for spp in (0, 1, 7, 100, 1024):
+            r = [sharding.spp_range(k, world, spp) for k in range(world)]
+            assert r[0][0] == 0 and sum(n for _, n in r) == spp
+            for (b0, n0), (b1, _) in zip(r, r[1:]):
+                assert b0 + n0 == b1
+    assert [sharding.spp_range(k, 8, 1024) for k in (0, 7)] == [(0, 128), (896, 128)]

@@ -1,0 +1,117 @@
+"""GPU vs the committed fixtures under tests/golden/ (no live oracle involved), plus the statistical
+image check of north_star: with different RNG streams the converged image matches the oracle's within
+the noise floor measured between two oracle seeds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from raytracinginaweekend_amd import capi, scene
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def world(name):
+    return {"cornell": lambda: scene.cornell_box(1.0), "two_boxes": lambda: scene.cornell_two_boxes(1.0),
+            "spheres4": lambda: scene.spheres_world(2.0, small_spheres=False), "spheres": lambda: scene.spheres_world(1.5)}[name]()
+
+
+def test_golden_prim_hits(gpu):
+    g = gold("f1_prim_hits.npz")
+    for key in [k for k in g.files if k.endswith("_hit") and not k.startswith("aabb")]:
+        wn, p = key.rsplit("_", 2)[0], int(key.rsplit("_", 2)[1])
+        s, _ = world(wn)
+        gpu.upload_scene(s)
+        sph = s.kind[p] == capi.PRIM_SPHERE
+        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, FLT_MAX), g[key], key, uv_tol=2e-6 if sph else None)
+        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, 4.0), g[key + "4"], key + "4", uv_tol=2e-6 if sph else None)
+    assert np.array_equal(gpu.aabb_hit_batch(g["aabb_min"], g["aabb_max"], g["aabb_org"], g["aabb_dir"], 0.001, FLT_MAX), g["aabb_hit"])
+    assert np.array_equal(gpu.aabb_hit_batch(g["aabb_min"], g["aabb_max"], g["aabb_org"], g["aabb_dir"], 0.001, 3.0), g["aabb_hit3"])
+
+
+def test_golden_world_hits(gpu):
+    g = gold("f2_world_hits.npz")
+    for wn in ("cornell", "two_boxes", "spheres4", "spheres"):
+        s, _ = world(wn)
+        s.set_bvh(g[f"{wn}_node_min"], g[f"{wn}_node_max"], g[f"{wn}_left"], g[f"{wn}_right"], int(g[f"{wn}_root"]))
+        gpu.upload_scene(s)
+        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, 0), g[f"{wn}_bvh"], wn + " bvh", uv_tol=2e-6)
+        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), g[f"{wn}_list"], wn + " list", uv_tol=2e-6)
+
+
+def test_golden_scatter_and_camera(gpu):
+    g = gold("f3_scatter.npz")
+    s, _ = world("cornell"); s.dielectric(2.4); s.metal((0.7, 0.6, 0.5), 0.0); s.metal((0.9, 0.9, 0.9), 5.0)
+    gpu.upload_scene(s)
+    o = gpu.scatter_batch(g["hits"], g["dir_in"], g["draws"])
+    assert np.array_equal(o["alive"], g["out_alive"]) and np.array_equal(o["consumed"], g["out_consumed"])
+    for k in ("atten", "org", "dir", "emit"):
+        H.assert_bits(o[k], g["out_" + k], "scatter." + k)
+    c = gold("f4_camera_rays.npz")
+    for name in ("cornell", "spheres", "spheres4"):
+        gpu.set_camera(capi.CameraStruct.from_buffer_copy(c[f"{name}_cam"].tobytes()))
+        o = gpu.camera_rays(c[f"{name}_uv"], c[f"{name}_draws"])
+        H.assert_bits(o["org"], c[f"{name}_org"], "cam.org"); H.assert_bits(o["dir"], c[f"{name}_dir"], "cam.dir")
+        assert np.array_equal(o["consumed"], c[f"{name}_consumed"])
+
+
+def test_golden_images(gpu):
+    g = gold("f5_images.npz")
+    f2 = gold("f2_world_hits.npz")
+    from tests import orc   # only to rebuild the fixture's BVH from its stored axis draws
+    for wn, (w, h) in {"cornell": (128, 128), "spheres4": (200, 100), "two_boxes": (64, 64)}.items():
+        s, cam = world(wn)
+        orc.bvh_build_reference(s, g[f"{wn}_axis_draws"])
+        gpu.upload_scene(s); gpu.set_camera(cam)
+        for tag, flags, spp in (("1spp", capi.FLAG_ONE_SPP, 1), ("normal", capi.FLAG_NORMAL_DISPLAY | capi.FLAG_ONE_SPP, 1), ("8spp", 0, 8)):
+            r = gpu.render(w, h, spp, 50, 0x5EED, flags)
+            assert np.array_equal(r["rgba8"], g[f"{wn}_{tag}_rgba8"]), (wn, tag)
+        H.assert_bits(r["sum"], g[f"{wn}_8spp_sum"], wn + " 8spp sum")
+
+
+def test_converged_image_within_noise_floor(gpu):
+    """Different RNG streams (another seed) at equal spp: PSNR(GPU, oracle) >= PSNR(oracle seed A, oracle
+    seed B) - 1 dB, the self-calibrated noise floor stored beside the fixture.  The oracle images were
+    rendered in the reference's recursive order; the device uses forward order."""
+    side = json.load(open(os.path.join(GOLD, "f6_converged.json")))
+    g = gold("f6_converged.npz")
+    for wn, meta in side.items():
+        s, cam = world(wn)
+        gpu.upload_scene(s); gpu.set_camera(cam)
+        r = gpu.render(meta["width"], meta["height"], meta["spp"], 50, 303, capi.FLAG_ACCEL_AUTO)
+        img = np.clip(r["pixels"], 0, 1)
+        for seed in meta["seeds"]:
+            p = H.psnr(img, g[f"{wn}_seed{seed}"].astype(np.float32))
+            assert p >= meta["mutual_psnr_db"] - 1.0, (wn, seed, p, meta["mutual_psnr_db"])
+
+
+def test_full_size_properties(gpu):
+    """BASELINE config sizes, through size-independent properties: sample ranges compose exactly, the
+    image is deterministic run to run, ray statistics match the survey's, and the light is where it is."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w = h = 1024
+    a = gpu.render(w, h, 16, 50, 0x5EED, capi.FLAG_ACCEL_AUTO)
+    b = gpu.render(w, h, 16, 50, 0x5EED, capi.FLAG_ACCEL_AUTO)
+    assert a["sum"].tobytes() == b["sum"].tobytes()                      # no atomics on floats: run-to-run identical
+    st = a["stats"]
+    assert st.samples == w * h * 16 and 6.4 < st.rays / st.samples < 6.7  # 6.57 rays per sample
+    assert list(st.depth_hist)[0] == st.samples and sum(list(st.depth_hist)) == st.rays
+    assert a["rgba8"][:, :, 3].min() == 255
+    assert a["rgba8"][20:40, 450:570, :3].min() == 255                    # the ceiling light saturates
+    assert a["rgba8"][400:600, 30:60, 0].mean() > 2 * a["rgba8"][400:600, 30:60, 1].mean()      # -x wall is red
+    assert a["rgba8"][400:600, 960:990, 1].mean() > 2 * a["rgba8"][400:600, 960:990, 0].mean()  # +x wall is green
+    # C3-sized frame of the random-spheres world through the BVH, 2 spp: finite, sky at the top
+    s3, cam3 = scene.spheres_world(1.5)
+    gpu.upload_scene(s3); gpu.set_camera(cam3)
+    c = gpu.render(1200, 800, 2, 50, 1, capi.FLAG_ACCEL_AUTO)
+    assert np.isfinite(c["sum"]).all() and 2.4 < c["stats"].rays / c["stats"].samples < 3.0
+    assert np.allclose(c["pixels"][0, 0], np.sqrt(np.float32([0.85, 0.9, 1.0])), atol=1e-6)
