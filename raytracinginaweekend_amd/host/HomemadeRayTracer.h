@@ -1,0 +1,45 @@
+// HomemadeRayTracer.h -- the seam (reference HomemadeRayTracer.h:11-33).  TraceRay flattens the world,
+// uploads it through the C ABI of include/mirt.h and renders on the MI355X; there is no CPU path.
+#pragma once
+#include "Vec3.h"
+#include "../../include/mirt.h"
+
+class OutputImage;
+class InputListener;
+class SimpleCamera;
+class World;
+
+class HomemadeRayTracer
+{
+public:
+	HomemadeRayTracer(InputListener *inputListener, OutputImage *image, const World *world);
+	~HomemadeRayTracer();
+
+	void OnInit();
+	void OnUpdate(const SimpleCamera *camera, OutputImage *image);
+	void OnDestroy();
+	void HelpInfo();
+	void TraceRay(const SimpleCamera *camera, OutputImage *image);
+
+	// SAMPLE_PER_PIXEL / MAX_SAMPLE_DEPTH (reference HomemadeRayTracer.cpp:21-22) at run time, plus what
+	// the reference cannot express: a seed, the GPU to use, and the toggles without key events
+	void SetSamplesPerPixel(UINT32 spp) { m_spp = spp; }
+	void SetMaxDepth(UINT32 depth) { m_maxDepth = depth; }
+	void SetSeed(UINT64 seed) { m_seed = seed; }
+	void SetDevice(int device) { m_device = device; }
+	void Enable1SPP(BOOL on) { m_enable1SPP = on; }
+	void EnableNormalDisplay(BOOL on) { m_enableNormalDisplay = on; }
+	const mirt_stats &LastStats() const { return m_stats; }
+
+private:
+	InputListener *m_inputListener{ nullptr };
+	BOOL           m_enableNormalDisplay{ FALSE };
+	BOOL           m_enable1SPP{ TRUE };
+	const World   *m_world{ nullptr };
+	UINT32         m_spp{ 100 }, m_maxDepth{ 50 };
+	UINT64         m_seed{ 0x5EED };
+	int            m_device{ 0 };
+	mirt_ctx      *m_ctx{ nullptr };
+	const World   *m_uploadedWorld{ nullptr };
+	mirt_stats     m_stats{};
+};

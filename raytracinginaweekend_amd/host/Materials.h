@@ -1,0 +1,68 @@
+// Materials.h -- the four materials of the reference (RayTracer/RayTracer/Materials.h:7-124) as
+// parameter holders.  Scatter() runs on the device (rt_device.h scatter); the D3D12 half is dropped.
+#pragma once
+#include "Vec3.h"
+#include "../../include/mirt.h"
+
+enum MaterialID
+{
+	MID_DIFFUSE_LIGHT = 0,
+	MID_LAMBERTIAN,
+	MID_METAL,
+	MID_DIELECTRIC,
+
+	MID_COUNT
+};
+
+class ITexture2D;
+
+struct FlatMaterial { uint32_t kind; float albedo[3]; float fuzz, ior; float emit[3]; };
+
+class IMaterial
+{
+public:
+	virtual ~IMaterial() = default;
+	virtual MaterialID GetID() const = 0;
+	virtual FlatMaterial Flatten() const = 0;
+};
+
+class Lambertian : public IMaterial
+{
+public:
+	const ITexture2D *m_albedo{ nullptr };
+	explicit Lambertian(const ITexture2D *albedo) : m_albedo(albedo) {}
+	MaterialID GetID() const override { return GetStaticID(); }
+	static MaterialID GetStaticID() { return MID_LAMBERTIAN; }
+	FlatMaterial Flatten() const override;
+};
+
+class Metal : public IMaterial
+{
+public:
+	float m_fuzziness;
+	ITexture2D *m_albedo{ nullptr };
+	Metal(ITexture2D *albedo, float fuzziness);
+	MaterialID GetID() const override { return GetStaticID(); }
+	static MaterialID GetStaticID() { return MID_METAL; }
+	FlatMaterial Flatten() const override;
+};
+
+class Dielectric : public IMaterial
+{
+public:
+	float m_refractiveIndex;
+	explicit Dielectric(float refractiveIndex) : m_refractiveIndex(refractiveIndex) {}
+	MaterialID GetID() const override { return GetStaticID(); }
+	static MaterialID GetStaticID() { return MID_DIELECTRIC; }
+	FlatMaterial Flatten() const override;
+};
+
+class DiffuseLight : public IMaterial
+{
+public:
+	Vec3 m_intensity;
+	explicit DiffuseLight(const Vec3 intensity) : m_intensity(intensity) {}
+	MaterialID GetID() const override { return GetStaticID(); }
+	static MaterialID GetStaticID() { return MID_DIFFUSE_LIGHT; }
+	FlatMaterial Flatten() const override;
+};

@@ -1,0 +1,681 @@
+// host.cpp -- implementation of the drop-in C++ scene API (headers in this directory carry the
+// reference's class and method names) on top of the C ABI of include/mirt.h.
+//
+// What runs here: scene construction (World::ConstructWorld, the object factories, the material
+// table), bounding boxes and the SimpleObjectBVHNode build, camera set-up, flattening to mirt_scene,
+// and the image sink.  What does not: Hit / Scatter / GetRay / Sample -- those are the HIP kernels.
+// Citations are relative to /root/reference/RayTracer/RayTracer/.
+#include "stdafx.h"
+
+#include <algorithm>
+#include <fstream>
+#include <random>
+#include <stdexcept>
+#include <sys/stat.h>
+
+#include "Hitables.h"
+#include "HomemadeRayTracer.h"
+#include "InputListener.h"
+#include "LightSources.h"
+#include "Materials.h"
+#include "OutputImage.h"
+#include "PPMImageMaker.h"
+#include "Randomizer.h"
+#include "Resouces.h"
+#include "SimpleCamera.h"
+#include "SimpleObject.h"
+#include "SimpleTexture2D.h"
+#include "World.h"
+
+using namespace std;
+
+// =========================================================================================== Randomizer
+namespace {
+struct HostStream {
+	uint32_t key[2]; uint32_t block = 0; uint32_t buf[4]; int left = 0; bool seeded = false;
+	void seed(uint64_t s) { key[0] = (uint32_t)s; key[1] = (uint32_t)(s >> 32); block = 0; left = 0; seeded = true; }
+	uint32_t next()
+	{
+		if (!seeded) { std::random_device rd; seed(((uint64_t)rd() << 32) | rd()); }
+		if (left == 0) {
+			uint32_t c0 = block++, c1 = 0, c2 = 0, c3 = 0x5CE9E, k0 = key[0], k1 = key[1];
+			for (int r = 0; r < 10; ++r) {                     // Philox4x32-10
+				uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+				uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+				c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+				k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+			}
+			buf[0] = c0; buf[1] = c1; buf[2] = c2; buf[3] = c3; left = 4;
+		}
+		return buf[4 - left--];
+	}
+} g_stream;
+}
+
+void Randomizer::Seed(UINT64 seed) { g_stream.seed(seed); }
+UINT32 Randomizer::Raw() { return g_stream.next(); }
+float Randomizer::RandomMinMax(float mn, float mx)                       // Randomizer.h:9-17
+{
+	double r = (double)Raw() / 4294967296.0;
+	r = r * (mx - mn) + mn;
+	return (float)r;
+}
+float Randomizer::RandomMinMax2(float mn, float mx)                      // Randomizer.h:20-26
+{
+	double r = (double)Raw() / 4294967295.0;
+	r = r * (mx - mn) + mn;
+	return (float)r;
+}
+Vec3 Randomizer::RomdomInUnitSphere()                                    // Randomizer.h:40-48
+{
+	Vec3 p;
+	do { float x = RandomMinMax2(-1.0f, 1.0f), y = RandomMinMax2(-1.0f, 1.0f), z = RandomMinMax2(-1.0f, 1.0f); p = Vec3(x, y, z); } while (p.squared_length() >= 1.0f);
+	return p;
+}
+Vec3 Randomizer::RandomInUnitDisk()                                      // Randomizer.h:50-58
+{
+	Vec3 p;
+	do { float x = RandomMinMax2(-1.0f, 1.0f), y = RandomMinMax2(-1.0f, 1.0f); p = Vec3(x, y, 0.0f); } while (p.squared_length() >= 1.0f);
+	return p;
+}
+
+// =========================================================================================== FlatScene
+uint32_t FlatScene::MaterialIndex(const IMaterial *m)
+{
+	if (!m) throw std::runtime_error("FlatScene: hitable without a material");
+	auto it = m_matIndex.find(m);
+	if (it != m_matIndex.end()) return it->second;
+	FlatMaterial f = m->Flatten();
+	uint32_t row = (uint32_t)mat_kind.size();
+	mat_kind.push_back(f.kind); mat_fuzz.push_back(f.fuzz); mat_ior.push_back(f.ior);
+	for (int i = 0; i < 3; ++i) { mat_albedo.push_back(f.albedo[i]); mat_emit.push_back(f.emit[i]); }
+	m_matIndex[m] = row;
+	return row;
+}
+void FlatScene::PushCommon(const InstanceChain &c, uint32_t kind, uint32_t axes, const IMaterial *m)
+{
+	if (obj_first.empty()) throw std::runtime_error("FlatScene: primitive outside an object");
+	prim_kind.push_back(kind); prim_axes.push_back(axes); prim_mat.push_back(MaterialIndex(m));
+	for (int i = 0; i < 3; ++i) prim_off.push_back(c.off[i]);
+	for (int i = 0; i < 6; ++i) prim_rot.push_back(c.rot[i]);
+	obj_count.back()++;
+}
+void FlatScene::AddSphere(const InstanceChain &c, float radius, const IMaterial *m)
+{
+	if (c.has_rot) throw std::runtime_error("FlatScene: rotated spheres are not representable (a sphere at its own centre is rotation-invariant; drop the RotatedInstance)");
+	PushCommon(c, MIRT_PRIM_SPHERE, 0, m);
+	prim_geom.push_back(radius); for (int i = 0; i < 4; ++i) prim_geom.push_back(0.0f);
+}
+void FlatScene::AddRect(const InstanceChain &c, uint32_t aA, uint32_t bA, uint32_t cA, float a0, float a1, float b0, float b1, float cc, bool reverse, const IMaterial *m)
+{
+	PushCommon(c, MIRT_PRIM_RECT, MIRT_AXES_PACK(aA, bA, cA, reverse ? 1u : 0u, c.has_rot ? 1u : 0u), m);
+	prim_geom.push_back(a0); prim_geom.push_back(a1); prim_geom.push_back(b0); prim_geom.push_back(b1); prim_geom.push_back(cc);
+}
+void FlatScene::EndObject()
+{
+	if (obj_count.back() == 0) throw std::runtime_error("FlatScene: object without primitives");
+}
+mirt_scene FlatScene::View() const
+{
+	mirt_scene s{};
+	s.n_prims = (uint32_t)prim_kind.size(); s.prim_kind = prim_kind.data(); s.prim_off = prim_off.data(); s.prim_geom = prim_geom.data();
+	s.prim_axes = prim_axes.data(); s.prim_rot = prim_rot.data(); s.prim_mat = prim_mat.data();
+	s.n_objects = (uint32_t)obj_first.size(); s.obj_first = obj_first.data(); s.obj_count = obj_count.data();
+	s.n_mats = (uint32_t)mat_kind.size(); s.mat_kind = mat_kind.data(); s.mat_albedo = mat_albedo.data(); s.mat_fuzz = mat_fuzz.data();
+	s.mat_ior = mat_ior.data(); s.mat_emit = mat_emit.data();
+	s.n_nodes = (uint32_t)node_left.size(); s.node_min = node_min.data(); s.node_max = node_max.data();
+	s.node_left = node_left.data(); s.node_right = node_right.data(); s.root = root;
+	for (int i = 0; i < 3; ++i) s.ambient[i] = ambient[i];
+	return s;
+}
+
+// =========================================================================================== Hitables
+AABB SphereHitable::BoundingBox() const                                  // Hitables.cpp:56-60
+{
+	Vec3 r(m_radius, m_radius, m_radius);
+	return AABB(-r, r);
+}
+void SphereHitable::Flatten(FlatScene &out, const InstanceChain &chain) const
+{
+	if (m_center.x() != 0.0f || m_center.y() != 0.0f || m_center.z() != 0.0f) {
+		// a centre is a translation below the chain; fold it only when nothing else is there
+		if (chain.translated || chain.has_rot) throw std::runtime_error("SphereHitable: off-centre sphere inside an instance chain is not representable");
+		InstanceChain c = chain; c.translated = true; for (int i = 0; i < 3; ++i) c.off[i] = m_center[i];
+		out.AddSphere(c, m_radius, m_material);
+		return;
+	}
+	out.AddSphere(chain, m_radius, m_material);
+}
+
+AxisAlignedRectHitable::AxisAlignedRectHitable(UINT32 aAxisIndex, UINT32 bAxisIndex, float a0, float a1, float b0, float b1, float c, BOOL reverseFace)
+	: m_a0(a0), m_a1(a1), m_b0(b0), m_b1(b1), m_c(c), m_aAxisIndex(aAxisIndex), m_bAxisIndex(bAxisIndex), m_reverseFace(reverseFace)
+{
+	if (!(aAxisIndex < 3 && bAxisIndex < 3 && aAxisIndex != bAxisIndex)) throw std::invalid_argument("AxisAlignedRectHitable: invalid axes");
+	m_cAxisIndex = 3 - aAxisIndex - bAxisIndex;                          // the remaining axis (Hitables.cpp:84)
+	if (m_a0 > m_a1) std::swap(m_a0, m_a1);
+	if (m_b0 > m_b1) std::swap(m_b0, m_b1);
+}
+AABB AxisAlignedRectHitable::BoundingBox() const                         // Hitables.cpp:117-128
+{
+	Vec3 mn(0, 0, 0), mx(0, 0, 0);
+	mn.set(m_aAxisIndex, m_a0); mx.set(m_aAxisIndex, m_a1);
+	mn.set(m_bAxisIndex, m_b0); mx.set(m_bAxisIndex, m_b1);
+	mn.set(m_cAxisIndex, m_c - 0.0001f); mx.set(m_cAxisIndex, m_c + 0.0001f);
+	return AABB(mn, mx);
+}
+void AxisAlignedRectHitable::Flatten(FlatScene &out, const InstanceChain &chain) const
+{
+	out.AddRect(chain, m_aAxisIndex, m_bAxisIndex, m_cAxisIndex, m_a0, m_a1, m_b0, m_b1, m_c, m_reverseFace != FALSE, m_material);
+}
+
+void HitableCombo::BindMaterial(IMaterial *m) { for (UINT32 i = 0; i < m_hitableCount; ++i) m_hitableList[i]->BindMaterial(m); }
+AABB HitableCombo::BoundingBox() const                                   // Hitables.cpp:152-161
+{
+	if (!m_hitableCount) throw std::runtime_error("HitableCombo: empty");
+	AABB box = m_hitableList[0]->BoundingBox();
+	for (UINT32 i = 1; i < m_hitableCount; ++i) box = CombineAABB(m_hitableList[i]->BoundingBox(), box);
+	return box;
+}
+void HitableCombo::Flatten(FlatScene &out, const InstanceChain &chain) const
+{
+	for (UINT32 i = 0; i < m_hitableCount; ++i) {
+		if (!dynamic_cast<AxisAlignedRectHitable *>(m_hitableList[i])) throw std::runtime_error("HitableCombo: only rect faces are representable on the device");
+		m_hitableList[i]->Flatten(out, chain);
+	}
+}
+
+AABB TranslatedInstance::BoundingBox() const                             // Hitables.cpp:175-180
+{
+	AABB b = m_hitable->BoundingBox();
+	return AABB(b.m_min + m_offset, b.m_max + m_offset);
+}
+void TranslatedInstance::Flatten(FlatScene &out, const InstanceChain &chain) const
+{
+	if (chain.translated || chain.has_rot) throw std::runtime_error("TranslatedInstance must be the outermost instance (Translate o RotZ o RotY o RotX o leaf)");
+	InstanceChain c = chain; c.translated = true;
+	for (int i = 0; i < 3; ++i) c.off[i] = m_offset[i];
+	m_hitable->Flatten(out, c);
+}
+
+RotatedInstance::RotatedInstance(IHitable *hitable, float angle, UINT32 rotateAxis)    // Hitables.cpp:182-239
+	: TransformedInstance(hitable), m_sinTheta(sinf(angle)), m_cosTheta(cosf(angle)), m_cAxisIndex(rotateAxis)
+{
+	if (rotateAxis == 0) { m_aAxisIndex = 1; m_bAxisIndex = 2; m_OP = -1.0f; }
+	else if (rotateAxis == 1) { m_aAxisIndex = 0; m_bAxisIndex = 2; m_OP = 1.0f; }
+	else { m_cAxisIndex = 2; m_aAxisIndex = 0; m_bAxisIndex = 1; m_OP = -1.0f; }
+	m_oppositeOP = -m_OP;
+	AABB in = m_hitable->BoundingBox();
+	Vec3 mn(FLT_MAX, FLT_MAX, FLT_MAX), mx(-FLT_MAX, -FLT_MAX, -FLT_MAX);
+	for (UINT32 corner = 0; corner < 8; ++corner) {                      // i,j,k of the reference = bits 2,1,0
+		UINT32 i = (corner >> 2) & 1, j = (corner >> 1) & 1, k = corner & 1;
+		float a = i * in.m_max[m_aAxisIndex] + (1 - i) * in.m_min[m_aAxisIndex];
+		float b = j * in.m_max[m_bAxisIndex] + (1 - j) * in.m_min[m_bAxisIndex];
+		float c = k * in.m_max[m_cAxisIndex] + (1 - k) * in.m_min[m_cAxisIndex];
+		Vec3 t(0, 0, 0);
+		t.set(m_aAxisIndex, m_cosTheta * a + m_OP * m_sinTheta * b);
+		t.set(m_bAxisIndex, -m_OP * m_sinTheta * a + m_cosTheta * b);
+		t.set(m_cAxisIndex, c);
+		for (UINT32 ax = 0; ax < 3; ++ax) { if (t[ax] > mx[ax]) mx.set(ax, t[ax]); if (t[ax] < mn[ax]) mn.set(ax, t[ax]); }
+	}
+	m_boundingBox = AABB(mn, mx);
+}
+void RotatedInstance::Flatten(FlatScene &out, const InstanceChain &chain) const
+{
+	if ((int)m_cAxisIndex >= chain.innermost_axis) throw std::runtime_error("RotatedInstance chain must be ordered z, y, x from the outside in");
+	InstanceChain c = chain; c.has_rot = true; c.innermost_axis = (int)m_cAxisIndex;
+	c.rot[2 * m_cAxisIndex] = m_sinTheta; c.rot[2 * m_cAxisIndex + 1] = m_cosTheta;
+	m_hitable->Flatten(out, c);
+}
+
+// =========================================================================================== Materials
+static void single_colour(const ITexture2D *t, float out[3])
+{
+	if (!t) throw std::runtime_error("material without a texture");
+	if (!t->IsSingleColor()) throw std::runtime_error("image textures are not on the device path yet (SURVEY.md section 8f, rank 1)");
+	Vec3 c = t->Sample(0.0f, 0.0f);
+	out[0] = c.r(); out[1] = c.g(); out[2] = c.b();
+}
+FlatMaterial Lambertian::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_LAMBERTIAN; single_colour(m_albedo, f.albedo); return f; }
+Metal::Metal(ITexture2D *albedo, float fuzziness) : m_albedo(albedo)     // Materials.cpp:93-97
+{
+	m_fuzziness = (fuzziness < 1.0f) ? ((fuzziness >= 0.0f) ? fuzziness : 0.0f) : 1.0f;
+}
+FlatMaterial Metal::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_METAL; single_colour(m_albedo, f.albedo); f.fuzz = m_fuzziness; return f; }
+FlatMaterial Dielectric::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_DIELECTRIC; f.ior = m_refractiveIndex; return f; }
+FlatMaterial DiffuseLight::Flatten() const
+{
+	FlatMaterial f{}; f.kind = MIRT_MAT_DIFFUSE_LIGHT;
+	f.emit[0] = m_intensity.x(); f.emit[1] = m_intensity.y(); f.emit[2] = m_intensity.z();
+	return f;
+}
+
+// =========================================================================================== Objects
+Object::~Object() { delete m_hitable; m_hitable = nullptr; }
+AABB Object::BoundingBox() const { return m_hitable->BoundingBox(); }
+int32_t Object::Flatten(FlatScene &out) const
+{
+	auto seen = out.objIndex.find(this);                 // World::Flatten lists the objects in creation order first
+	if (seen != out.objIndex.end()) return seen->second;
+	out.objIndex[this] = ~(int32_t)out.obj_first.size();
+	out.BeginObject();
+	m_hitable->Flatten(out, InstanceChain{});
+	out.EndObject();
+	return ~(int32_t)(out.obj_first.size() - 1);
+}
+
+SimpleObjectSphere::SimpleObjectSphere(const Vec3 &center, float radius, Mesh *mesh, IMaterial *material, World *world)   // SimpleObject.cpp:129-139
+{
+	m_translation = center; m_scaling = Vec3(radius, radius, radius); m_rotation = Vec3(0.0f, 0.0f, 0.0f);
+	m_mesh = mesh; m_material = material; m_world = world;
+	m_hitable = new TranslatedInstance(new SphereHitable(Vec3(0.0f, 0.0f, 0.0f), radius), m_translation);
+	m_hitable->BindMaterial(material);
+}
+
+static IHitable *wrap_chain(IHitable *leaf, const Vec3 &rotation, const Vec3 &translation)   // SimpleObject.cpp:173-181
+{
+	return new TranslatedInstance(new RotatedInstance(new RotatedInstance(new RotatedInstance(leaf, rotation[0], 0), rotation[1], 1), rotation[2], 2), translation);
+}
+
+SimpleObjectRect::SimpleObjectRect(SimpleObjectRectAlignAxes axes, const Vec3 &center, const Vec3 &rotation, float width, float height, BOOL reverseFace,
+                                   Mesh *mesh, IMaterial *material, World *world)                 // SimpleObject.cpp:141-184
+	: m_alignAxes(axes), m_reverseFace(reverseFace)
+{
+	m_translation = center; m_scaling = Vec3(width, height, 1.0f); m_rotation = rotation;
+	m_mesh = mesh; m_material = material; m_world = world;
+	UINT32 aA = (axes == ZY_RECT) ? 2 : 0, bA = (axes == XZ_RECT) ? 2 : 1;
+	float ha = width / 2.0f, hb = height / 2.0f;
+	m_hitable = wrap_chain(new AxisAlignedRectHitable(aA, bA, -ha, ha, -hb, hb, 0.0f, m_reverseFace), m_rotation, m_translation);
+	m_hitable->BindMaterial(material);
+}
+
+SimpleObjectCube::SimpleObjectCube(const Vec3 &center, const Vec3 &rotation, const Vec3 &size, Mesh *mesh, IMaterial *material, World *world)   // SimpleObject.cpp:249-279
+{
+	m_translation = center; m_scaling = size; m_rotation = rotation; m_mesh = mesh; m_material = material; m_world = world;
+	Vec3 lo = -size * 0.5f, hi = size * 0.5f;
+	struct F { UINT32 a, b; float a0, a1, b0, b1, c; BOOL rev; } faces[6] = {
+		{ 0, 2, lo.x(), hi.x(), lo.z(), hi.z(), hi.y(), FALSE }, { 0, 2, lo.x(), hi.x(), lo.z(), hi.z(), lo.y(), TRUE },
+		{ 0, 1, lo.x(), hi.x(), lo.y(), hi.y(), hi.z(), FALSE }, { 0, 1, lo.x(), hi.x(), lo.y(), hi.y(), lo.z(), TRUE },
+		{ 2, 1, lo.z(), hi.z(), lo.y(), hi.y(), hi.x(), FALSE }, { 2, 1, lo.z(), hi.z(), lo.y(), hi.y(), lo.x(), TRUE } };
+	for (int i = 0; i < 6; ++i) m_faceList[i] = new AxisAlignedRectHitable(faces[i].a, faces[i].b, faces[i].a0, faces[i].a1, faces[i].b0, faces[i].b1, faces[i].c, faces[i].rev);
+	m_hitable = wrap_chain(new HitableCombo(&m_faceList[0], 6), m_rotation, m_translation);
+	m_hitable->BindMaterial(material);
+}
+SimpleObjectCube::~SimpleObjectCube()
+{
+	for (auto &f : m_faceList) { delete f; f = nullptr; }
+}
+
+// SimpleObject.cpp:293-346: random axis, descending by translation, split at floor(n/2).  stable_sort
+// pins the order of ties, which std::sort leaves unspecified.
+SimpleObjectBVHNode::SimpleObjectBVHNode(std::vector<Object *> objects)
+{
+	if (objects.empty()) throw std::invalid_argument("SimpleObjectBVHNode: no objects");
+	UINT32 axis = UINT32(3 * Randomizer::RandomUNorm());
+	if (axis > 2) axis = 2;
+	std::stable_sort(objects.begin(), objects.end(), [axis](Object *a, Object *b) { return b->m_translation[axis] < a->m_translation[axis]; });
+	size_t n = objects.size();
+	if (n == 1) { leftChild = objects[0]; rightChild = nullptr; m_bindingBox = leftChild->BoundingBox(); return; }
+	if (n == 2) { leftChild = objects[0]; rightChild = objects[1]; }
+	else {
+		size_t half = static_cast<size_t>(n * 0.5f);
+		leftChild = new SimpleObjectBVHNode(std::vector<Object *>(objects.begin(), objects.begin() + half));
+		rightChild = new SimpleObjectBVHNode(std::vector<Object *>(objects.begin() + half, objects.end()));
+	}
+	m_bindingBox = CombineAABB(leftChild->BoundingBox(), rightChild->BoundingBox());
+}
+SimpleObjectBVHNode::~SimpleObjectBVHNode() { delete leftChild; delete rightChild; leftChild = rightChild = nullptr; }
+int32_t SimpleObjectBVHNode::Flatten(FlatScene &out) const
+{
+	int32_t me = (int32_t)out.node_left.size();
+	out.node_left.push_back(MIRT_CHILD_NONE); out.node_right.push_back(MIRT_CHILD_NONE);
+	for (int i = 0; i < 3; ++i) { out.node_min.push_back(m_bindingBox.m_min[i]); out.node_max.push_back(m_bindingBox.m_max[i]); }
+	int32_t l = leftChild ? leftChild->Flatten(out) : MIRT_CHILD_NONE;
+	int32_t r = rightChild ? rightChild->Flatten(out) : MIRT_CHILD_NONE;
+	out.node_left[me] = l; out.node_right[me] = r;
+	return me;
+}
+
+// =========================================================================================== Resources
+void Resources::Load() { LoadMaterials(); }
+void Resources::Unload()
+{
+	for (auto *m : m_materials) delete m;
+	for (auto *t : m_textures) delete t;
+	m_materials.clear(); m_textures.clear();
+}
+IMaterial *Resources::GetTheMaterial(MaterialUniqueID id) const
+{
+	if ((size_t)id >= m_materials.size()) throw std::out_of_range("Resources::GetTheMaterial");
+	return m_materials[id];
+}
+void Resources::LoadMaterials()                                          // Resouces.cpp:104-209, same order = same ids
+{
+	auto colour = [&](float r, float g, float b) { ITexture2D *t = new SimpleTexture2D_SingleColor(Vec3(r, g, b)); m_textures.push_back(t); return t; };
+	for (int i = 0; i < MATERIAL_ID_RANDOM_LAMBERTIAN_COUNT; ++i) {
+		float c[3];
+		for (int k = 0; k < 3; ++k) { float u0 = Randomizer::RandomUNorm(); float u1 = Randomizer::RandomUNorm(); c[k] = u0 * u1; }
+		m_materials.push_back(new Lambertian(colour(c[0], c[1], c[2])));
+	}
+	for (int i = 0; i < MATERIAL_ID_RANDOM_METAL_COUNT; ++i) {
+		float c[3];
+		for (int k = 0; k < 3; ++k) c[k] = 0.5f * (1 + Randomizer::RandomUNorm());
+		float fuzz = 0.5f * Randomizer::RandomUNorm();
+		m_materials.push_back(new Metal(colour(c[0], c[1], c[2]), fuzz));
+	}
+	m_materials.push_back(new Lambertian(colour(0.5f, 0.5f, 0.5f)));      // MATERIAL_ID_LAMBERTIAN0
+	m_materials.push_back(new Lambertian(colour(0.4f, 0.2f, 0.1f)));      // 1
+	m_materials.push_back(new Lambertian(colour(0.65f, 0.05f, 0.05f)));   // 2
+	m_materials.push_back(new Lambertian(colour(0.73f, 0.73f, 0.73f)));   // 3
+	m_materials.push_back(new Lambertian(colour(0.12f, 0.45f, 0.15f)));   // 4
+	m_materials.push_back(new Metal(colour(0.7f, 0.6f, 0.5f), 0.0f));     // MATERIAL_ID_METAL
+	m_materials.push_back(new Dielectric(1.5f));                          // MATERIAL_ID_DIELECTRIC
+	// the two TGA-textured materials (Resouces.cpp:166-176) are unused by both worlds; until image
+	// textures are on the device path their slots hold mid-grey stand-ins so the later ids keep their values
+	m_materials.push_back(new Lambertian(colour(0.5f, 0.5f, 0.5f)));      // MATERIAL_ID_IMAGE_BASED_GROUND_SOIL
+	m_materials.push_back(new Metal(colour(0.5f, 0.5f, 0.5f), 0.7f));     // MATERIAL_ID_IMAGE_BASED_METAL_CHECKER
+	m_materials.push_back(new DiffuseLight(Vec3(4.0f, 4.0f, 4.0f)));      // WHITE
+	m_materials.push_back(new DiffuseLight(Vec3(15.0f, 15.0f, 15.0f)));   // BRIGHT
+	m_materials.push_back(new DiffuseLight(Vec3(4.0f, 0.0f, 0.0f)));      // RED
+	m_materials.push_back(new DiffuseLight(Vec3(0.0f, 4.0f, 0.0f)));      // GREEN
+	m_materials.push_back(new DiffuseLight(Vec3(0.0f, 0.0f, 4.0f)));      // BLUE
+	m_materials.push_back(new Lambertian(colour(0.19f, 0.2f, 0.14f)));    // MATERIAL_ID_CORNELL_BALL1
+	m_materials.push_back(new Metal(colour(0.26f, 0.06f, 0.06f), 0.20f)); // MATERIAL_ID_CORNELL_BALL2
+}
+
+// =========================================================================================== LightSources
+LightSources::LightSources(World *world, std::vector<Object *> &objects, const Vec3 &ambientLight)   // LightSources.cpp:14-30
+	: m_world(world), m_ambientLight(ambientLight)
+{
+	for (Object *o : objects) if (o->m_material && o->m_material->GetID() == MID_DIFFUSE_LIGHT) m_lightSources.push_back(o);
+	m_lightSourceCount = (UINT32)m_lightSources.size();
+	m_lightSourceCountX = m_lightSourceCount == 0 ? 1 : m_lightSourceCount;
+}
+
+// =========================================================================================== World
+void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // World.cpp:15-110
+{
+	m_resources = new Resources();
+	m_resources->Load();
+	auto mat = [&](MaterialUniqueID id) { return m_resources->GetTheMaterial(id); };
+	std::vector<Object *> objects;
+	const Vec3 none(0.0f, 0.0f, 0.0f);
+	if (wid == WORLD_ID_RANDOM_SPHERES || wid == WORLD_ID_FOUR_SPHERES) {
+		objects.push_back(new SimpleObjectSphere(Vec3(0.0f, -1000.0f, -0.0f), 1000.0f, nullptr, mat(MATERIAL_ID_LAMBERTIAN0), this));
+		objects.push_back(new SimpleObjectSphere(Vec3(-4.0f, 1.0f, 0.0f), 1.0f, nullptr, mat(MATERIAL_ID_LAMBERTIAN1), this));
+		objects.push_back(new SimpleObjectSphere(Vec3(0.0f, 1.0f, 0.0f), 1.0f, nullptr, mat(MATERIAL_ID_DIELECTRIC), this));
+		objects.push_back(new SimpleObjectSphere(Vec3(4.0f, 1.0f, 0.0f), 1.0f, nullptr, mat(MATERIAL_ID_METAL), this));
+		if (wid == WORLD_ID_RANDOM_SPHERES) {
+			for (int a = -11; a < 11; a++) for (int b = -11; b < 11; b++) {
+				float chooseMat = Randomizer::RandomUNorm();
+				float cx = a + 0.9f * Randomizer::RandomUNorm();
+				float cz = b + 0.9f * Randomizer::RandomUNorm();
+				Vec3 center(cx, 0.2f, cz);
+				if ((center - Vec3(4.0f, 0.2f, 0.0f)).length() > 0.9f) {
+					MaterialUniqueID id = MATERIAL_ID_DIELECTRIC;
+					if (chooseMat < 0.8f) id = (MaterialUniqueID)(UINT32)(MATERIAL_ID_RANDOM_LAMBERTIAN_START + Randomizer::RandomUNorm() * MATERIAL_ID_RANDOM_LAMBERTIAN_COUNT);
+					else if (chooseMat < 0.95f) id = (MaterialUniqueID)(UINT32)(MATERIAL_ID_RANDOM_METAL_START + Randomizer::RandomUNorm() * MATERIAL_ID_RANDOM_METAL_COUNT);
+					objects.push_back(new SimpleObjectSphere(center, 0.2f, nullptr, mat(id), this));
+				}
+			}
+		}
+		m_lightSources = new LightSources(this, objects, Vec3(0.85f, 0.9f, 1.0f));
+		camera->Initialize(Vec3(11.0f, 2.0f, 3.0f), Vec3(0.0f, 0.6f, 0.0f), 20.0f, 1.0f, 10000.0f, 0.1f, 10.0f, 1.0f);
+	} else if (wid == WORLD_ID_CORNELL_BOX || wid == WORLD_ID_CORNELL_TWO_BOXES) {
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 0.99f, 0.0f), none, 0.65f, 0.65f, TRUE, nullptr, mat(MATERIAL_ID_LIGHTSOURCE_BRIGHT), this));
+		objects.push_back(new SimpleObjectRect(ZY_RECT, Vec3(1.0f, 0.0f, 0.0f), none, 2.0f, 2.0f, TRUE, nullptr, mat(MATERIAL_ID_LAMBERTIAN4), this));
+		objects.push_back(new SimpleObjectRect(ZY_RECT, Vec3(-1.0f, 0.0f, 0.0f), none, 2.0f, 2.0f, FALSE, nullptr, mat(MATERIAL_ID_LAMBERTIAN2), this));
+		objects.push_back(new SimpleObjectRect(XY_RECT, Vec3(0.0f, 0.0f, -1.0f), none, 2.0f, 2.0f, FALSE, nullptr, mat(MATERIAL_ID_LAMBERTIAN3), this));
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 1.0f, 0.0f), none, 2.0f, 2.0f, TRUE, nullptr, mat(MATERIAL_ID_LAMBERTIAN3), this));
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, -1.0f, 0.0f), none, 2.0f, 2.0f, FALSE, nullptr, mat(MATERIAL_ID_LAMBERTIAN3), this));
+		if (wid == WORLD_ID_CORNELL_TWO_BOXES) {                             // World.cpp:84-89
+			float height = 1.2f;
+			objects.push_back(new SimpleObjectCube(Vec3(-0.3f, -1.0f + height * 0.5f, -0.4f), Vec3(0.0f, 0.3f, 0.0f), Vec3(0.6f, height, 0.6f), nullptr, mat(MATERIAL_ID_LAMBERTIAN3), this));
+			height = 0.6f;
+			objects.push_back(new SimpleObjectCube(Vec3(0.32f, -1.0f + height * 0.5f, 0.4f), Vec3(0.0f, -0.3f, 0.0f), Vec3(height, height, height), nullptr, mat(MATERIAL_ID_LAMBERTIAN3), this));
+			camera->Initialize(Vec3(0.0f, 0.0f, 4.0f), Vec3(0.0f, 0.0f, 0.0f), 40.0f, 1.0f, 10000.0f, 0.0f, 10.0f, 1.0f);
+		} else {                                                             // World.cpp:91-96
+			float r = 0.32f;
+			objects.push_back(new SimpleObjectSphere(Vec3(-0.38f, -1.0f + r, -0.35f), r, nullptr, mat(MATERIAL_ID_CORNELL_BALL1), this));
+			objects.push_back(new SimpleObjectSphere(Vec3(0.0f, -1.0f + r, 0.50f), r, nullptr, mat(MATERIAL_ID_DIELECTRIC), this));
+			objects.push_back(new SimpleObjectSphere(Vec3(0.38f, -1.0f + r, -0.35f), r, nullptr, mat(MATERIAL_ID_CORNELL_BALL2), this));
+			camera->Initialize(Vec3(0.0f, 0.64f, 4.63f), Vec3(0.0f, -0.26f, -1.0f), 30.0f, 1.0f, 10000.0f, 0.0f, 10.0f, 1.0f);
+		}
+		m_lightSources = new LightSources(this, objects, Vec3(0.0f, 0.0f, 0.0f));
+	} else {
+		throw std::invalid_argument("World::ConstructWorld: unknown world id");
+	}
+	m_objectsCount = objects.size();
+	m_objects = objects;
+	m_objectBVHTree = new SimpleObjectBVHNode(objects);
+}
+void World::DeconstructWorld()
+{
+	delete m_objectBVHTree; m_objectBVHTree = nullptr; m_objects.clear();
+	delete m_lightSources; m_lightSources = nullptr;
+	if (m_resources) { m_resources->Unload(); delete m_resources; m_resources = nullptr; }
+}
+void World::Flatten(FlatScene &out) const
+{
+	if (!m_objectBVHTree || !m_lightSources) throw std::runtime_error("World::Flatten: world not constructed");
+	for (const Object *o : m_objects) o->Flatten(out);   // object (and primitive) order = construction order, as in the reference's list
+	out.root = m_objectBVHTree->Flatten(out);
+	Vec3 amb = m_lightSources->GetAmbientLight();
+	for (int i = 0; i < 3; ++i) out.ambient[i] = amb[i];
+}
+
+// =========================================================================================== InputListener
+void InputListener::RegisterKey(UINT8 k) { m_keyStatus.emplace(k, KeyState{}); }
+BOOL InputListener::WhenPressKey(UINT8 k) { auto it = m_keyStatus.find(k); return it == m_keyStatus.end() ? FALSE : it->second.press; }
+BOOL InputListener::WhenReleaseKey(UINT8 k) { auto it = m_keyStatus.find(k); return it == m_keyStatus.end() ? FALSE : it->second.release; }
+BOOL InputListener::WhenHoldKey(UINT8 k) { auto it = m_keyStatus.find(k); return it == m_keyStatus.end() ? FALSE : it->second.hold; }
+void InputListener::NotifyKeyDown(UINT8 k)                               // InputListener.cpp:48-59
+{
+	auto it = m_keyStatus.find(k); if (it == m_keyStatus.end()) return;
+	KeyState &s = it->second;
+	s.press = !s.down; s.hold = s.down; s.release = FALSE; s.down = TRUE;
+}
+void InputListener::NotifyKeyUp(UINT8 k)                                 // InputListener.cpp:61-73
+{
+	auto it = m_keyStatus.find(k); if (it == m_keyStatus.end()) return;
+	KeyState &s = it->second;
+	s.press = FALSE; s.hold = FALSE; s.release = s.down; s.down = FALSE;
+}
+void InputListener::Clear() { for (auto &kv : m_keyStatus) { kv.second.press = FALSE; kv.second.release = FALSE; } }
+
+// =========================================================================================== SimpleCamera
+SimpleCamera::SimpleCamera(const World *world, InputListener *inputListener, float aspectRatio)
+	: m_aspectRatio(aspectRatio), m_world(world), m_inputListener(inputListener)
+{
+	if (m_inputListener) for (UINT8 k : { (UINT8)'H', (UINT8)'W', (UINT8)'A', (UINT8)'S', (UINT8)'D', (UINT8)VK_LEFT, (UINT8)VK_UP, (UINT8)VK_RIGHT, (UINT8)VK_DOWN, (UINT8)VK_ESCAPE }) m_inputListener->RegisterKey(k);
+}
+void SimpleCamera::Initialize(const Vec3 &lookFrom, const Vec3 &lookAt, float fov, float minZ, float maxZ, float aperture, float unitsPerSecond, float radiansPerSecond)
+{                                                                         // SimpleCamera.cpp:32-53
+	m_initialOrigin = lookFrom; m_initialFocus = lookAt; m_vup = Vec3(0.0f, 1.0f, 0.0f);
+	m_fov = fov; m_nearPlane = minZ; m_farPlane = maxZ; m_lensRadius = aperture / 2.0f;
+	Reset();
+	m_moveSpeed = unitsPerSecond; m_turnSpeed = radiansPerSecond;
+}
+void SimpleCamera::Reset()                                               // SimpleCamera.cpp:139-174
+{
+	m_origin = m_initialOrigin; m_focus = m_initialFocus;
+	Vec3 look = m_focus - m_origin;
+	float len = look.length();
+	if (len != 0.0f) {
+		m_pitch = -asinf(look.y() / len);
+		if (look.z() > 0.0f) m_yaw = atanf(look.x() / look.z());
+		else if (look.z() < 0.0f) m_yaw = atanf(look.x() / look.z()) + (float)M_PI;
+		else if (look.x() > 0.0f) m_yaw = (float)M_PI / 2.0f;
+		else if (look.x() < 0.0f) m_yaw = -(float)M_PI / 2.0f;
+	} else {
+		m_focus = m_origin + Vec3(0.0f, 0.0f, -1.0f); m_pitch = 0.0f; m_yaw = (float)M_PI;
+	}
+	InternalUpdate();
+}
+void SimpleCamera::InternalUpdate()                                      // SimpleCamera.cpp:177-191
+{
+	float focusDist = (m_origin - m_focus).length();
+	m_w = normalize(m_origin - m_focus);
+	m_u = normalize(cross(m_vup, m_w));
+	m_v = cross(m_w, m_u);
+	const float theta = m_fov * (float)M_PI / 180.0f;
+	const float halfH = tanf(theta / 2.0f) * focusDist;
+	const float halfW = halfH * m_aspectRatio;
+	m_viewTopLeftCorner = m_origin - halfW * m_u + halfH * m_v - focusDist * m_w;
+	m_viewHorizontal = 2.0f * halfW * m_u;
+	m_viewVertical = -2.0f * halfH * m_v;
+}
+void SimpleCamera::OnUpdate(float)
+{
+	if (m_inputListener && m_inputListener->WhenReleaseKey(VK_ESCAPE)) Reset();   // the fly controls are interactive-only
+	if (m_inputListener && m_inputListener->WhenReleaseKey('H')) HelpInfo();
+}
+void SimpleCamera::HelpInfo()
+{
+	cout << "[SimpleCamera] " << m_origin << " > " << m_focus << " fov " << m_fov << " aperture " << m_lensRadius * 2.0f << endl;
+}
+void SimpleCamera::Export(mirt_camera &c) const
+{
+	for (int i = 0; i < 3; ++i) {
+		c.origin[i] = m_origin[i]; c.top_left[i] = m_viewTopLeftCorner[i]; c.horizontal[i] = m_viewHorizontal[i];
+		c.vertical[i] = m_viewVertical[i]; c.u[i] = m_u[i]; c.v[i] = m_v[i];
+	}
+	c.lens_radius = m_lensRadius;
+}
+
+// =========================================================================================== OutputImage / PPM
+OutputImage::OutputImage(UINT32 width, UINT32 height, const char *name) : m_width(width), m_height(height), m_name(name)   // OutputImage.cpp:8-19
+{
+	m_aspectRatio = static_cast<float>(width) / static_cast<float>(height);
+	m_dataSizeInByte = (UINT64)m_width * m_height * m_pixelSizeInByte;
+	m_data = new UINT8[m_dataSizeInByte ? m_dataSizeInByte : 1]();
+}
+OutputImage::~OutputImage() { delete[] m_data; m_data = nullptr; }
+static inline UINT8 to_byte(float c) { float s = c * 255.0f; return (s == s) ? (UINT8)(static_cast<UINT32>(s) & 0xFF) : 0; }
+void OutputImage::RenderAsRainbow()                                      // OutputImage.cpp:31-49
+{
+	for (UINT32 j = 0; j < m_height; j++) for (UINT32 i = 0; i < m_width; i++) {
+		UINT8 *p = m_data + ((size_t)j * m_width + i) * 4;
+		p[0] = to_byte(float(i) / float(m_width - 1)); p[1] = to_byte(1.0f - float(j) / float(m_height - 1)); p[2] = to_byte(0.2f); p[3] = 255;
+	}
+	m_isDirty = TRUE;
+}
+void OutputImage::RenderAsRed()
+{
+	for (size_t i = 0; i < (size_t)m_width * m_height; i++) { UINT8 *p = m_data + i * 4; p[0] = 255; p[1] = 0; p[2] = 0; p[3] = 255; }
+	m_isDirty = TRUE;
+}
+void OutputImage::Render(const Vec3 *pixels, UINT32 pixelCount)           // OutputImage.cpp:62-88
+{
+	if (pixelCount && pixelCount != m_width * m_height) throw std::invalid_argument("OutputImage::Render: unmatching image size and data size");
+	for (size_t i = 0; i < (size_t)m_width * m_height; ++i) {
+		Vec3 col = pixels[i];
+		col.clamp(Vec3(0.0f, 0.0f, 0.0f), Vec3(1.0f, 1.0f, 1.0f));
+		UINT8 *p = m_data + i * 4;
+		p[0] = to_byte(col.r()); p[1] = to_byte(col.g()); p[2] = to_byte(col.b()); p[3] = 255;
+	}
+	m_isDirty = TRUE;
+}
+void OutputImage::Output()                                               // OutputImage.cpp:255-259
+{
+	std::string path = m_outputDir + "/" + m_name + ".ppm";
+	PPMImageMaker::OutputRGBA8ToFile(path.c_str(), m_width, m_height, m_data, m_dataSizeInByte);
+}
+void PPMImageMaker::OutputRGBA8ToFile(const char *fileName, UINT32 w, UINT32 h, const UINT8 *rgba8, UINT64 dataSizeInByte)
+{
+	if (!rgba8) throw std::invalid_argument("PPMImageMaker: invalid data ptr");
+	if (dataSizeInByte && dataSizeInByte != (UINT64)w * h * 4) throw std::invalid_argument("PPMImageMaker: unmatching image size and data size");
+	cout << "[PPMImageMaker] Save output image to PPM file: " << fileName << " ..." << endl;
+	if (mirt_write_ppm(fileName, w, h, rgba8) != MIRT_OK) throw std::runtime_error(std::string("PPMImageMaker: cannot write ") + fileName);
+	cout << "[PPMImageMaker] Done" << endl;
+}
+
+// =========================================================================================== HomemadeRayTracer
+HomemadeRayTracer::HomemadeRayTracer(InputListener *inputListener, OutputImage *, const World *world) : m_inputListener(inputListener), m_world(world) {}
+HomemadeRayTracer::~HomemadeRayTracer() { if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; }
+void HomemadeRayTracer::OnInit()                                          // HomemadeRayTracer.cpp:36-43
+{
+	cout << "[HomemadeRayTracer] Init" << endl;
+	if (m_inputListener) for (UINT8 k : { (UINT8)VK_SPACE, (UINT8)'H', (UINT8)'N', (UINT8)'M' }) m_inputListener->RegisterKey(k);
+}
+void HomemadeRayTracer::OnUpdate(const SimpleCamera *camera, OutputImage *image)   // HomemadeRayTracer.cpp:45-70
+{
+	if (!m_inputListener) return;
+	if (m_inputListener->WhenReleaseKey(VK_SPACE)) TraceRay(camera, image);
+	if (m_inputListener->WhenReleaseKey('H')) HelpInfo();
+	if (m_inputListener->WhenReleaseKey('N')) { m_enableNormalDisplay = !m_enableNormalDisplay; cout << "[HomemadeRayTracer][NormalDisplay] " << (m_enableNormalDisplay ? "Enabled" : "Disabled") << endl; }
+	if (m_inputListener->WhenReleaseKey('M')) { m_enable1SPP = !m_enable1SPP; cout << "[HomemadeRayTracer][1SPP] " << (m_enable1SPP ? "Enabled" : "Disabled") << endl; }
+}
+void HomemadeRayTracer::OnDestroy() { cout << "[HomemadeRayTracer] Destroy" << endl; if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; m_uploadedWorld = nullptr; }
+void HomemadeRayTracer::HelpInfo()
+{
+	cout << "=============HomemadeRayTracer (MI355X)============" << endl
+	     << "  [space] render  [n] normal display  [m] 1-SPP  [h] help" << endl
+	     << "[NormalDisplay] " << (m_enableNormalDisplay ? "Enabled" : "Disabled") << "  [1SPP] " << (m_enable1SPP ? "Enabled" : "Disabled")
+	     << "  [SPP] " << m_spp << "  [depth] " << m_maxDepth << endl;
+}
+void HomemadeRayTracer::TraceRay(const SimpleCamera *camera, OutputImage *image)   // HomemadeRayTracer.cpp:90-154
+{
+	if (!camera || !image || !m_world) throw std::invalid_argument("HomemadeRayTracer::TraceRay: null argument");
+	cout << "[HomemadeRayTracer] TraceRay ..." << endl;
+	cout << "[HomemadeRayTracer] SPP: " << (m_enable1SPP ? 1u : m_spp) << endl;
+	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_ctx)); };
+	if (!m_ctx) check(mirt_create(m_device, &m_ctx), "mirt_create");
+	if (m_uploadedWorld != m_world) {
+		FlatScene flat;
+		m_world->Flatten(flat);
+		mirt_scene view = flat.View();
+		check(mirt_upload_scene(m_ctx, &view), "mirt_upload_scene");
+		m_uploadedWorld = m_world;
+	}
+	mirt_camera cam; camera->Export(cam);
+	check(mirt_set_camera(m_ctx, &cam), "mirt_set_camera");
+	mirt_render_params p{};
+	p.width = image->m_width; p.height = image->m_height; p.spp_begin = 0; p.spp_count = m_spp; p.max_depth = m_maxDepth; p.seed = m_seed;
+	p.flags = MIRT_FLAG_ACCEL_AUTO | (m_enable1SPP ? MIRT_FLAG_ONE_SPP : 0u) | (m_enableNormalDisplay ? MIRT_FLAG_NORMAL_DISPLAY : 0u);
+	check(mirt_render(m_ctx, &p, nullptr, nullptr, image->m_data, &m_stats), "mirt_render");   // device resolve == OutputImage::Render
+	image->m_isDirty = TRUE;
+	cout << "[HomemadeRayTracer] Done (" << m_stats.rays << " rays, " << m_stats.device_ms << " ms on the GPU)" << endl;
+}
+
+// =========================================================================================== C shim for harnesses
+// Lets a ctypes harness build a reference world through the C++ API and read back the flattened
+// arrays (tests compare them with the Python mirror and the oracle's tree).
+struct mirt_host_world { World world; SimpleCamera *cam; InputListener input; FlatScene flat; mirt_scene view; mirt_camera mcam; std::string err; };
+extern "C" {
+mirt_host_world *mirt_host_world_create(int world_id, float aspect, uint64_t seed, char *err, size_t errlen)
+{
+	try {
+		auto *h = new mirt_host_world();
+		Randomizer::Seed(seed);
+		h->cam = new SimpleCamera(&h->world, &h->input, aspect);
+		h->world.ConstructWorld((WorldID)world_id, h->cam);
+		h->world.Flatten(h->flat);
+		h->view = h->flat.View();
+		h->cam->Export(h->mcam);
+		return h;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return nullptr; }
+}
+const mirt_scene *mirt_host_world_scene(const mirt_host_world *h) { return &h->view; }
+const mirt_camera *mirt_host_world_camera(const mirt_host_world *h) { return &h->mcam; }
+void mirt_host_world_destroy(mirt_host_world *h) { if (!h) return; h->world.DeconstructWorld(); delete h->cam; delete h; }
+// whole reference flow: ConstructWorld -> TraceRay -> image bytes (and optionally <dir>/<name>.ppm)
+int mirt_host_render(int world_id, uint32_t w, uint32_t h, uint32_t spp, uint32_t depth, uint64_t scene_seed, uint64_t seed, int one_spp, int normal,
+                     uint8_t *rgba8_out, const char *ppm_dir, char *err, size_t errlen)
+{
+	try {
+		InputListener input; OutputImage image(w, h, "OutputImage"); World world;
+		Randomizer::Seed(scene_seed);
+		SimpleCamera camera(&world, &input, image.m_aspectRatio);
+		world.ConstructWorld((WorldID)world_id, &camera);
+		HomemadeRayTracer rt(&input, &image, &world);
+		rt.OnInit();
+		rt.SetSamplesPerPixel(spp); rt.SetMaxDepth(depth); rt.SetSeed(seed); rt.Enable1SPP(one_spp); rt.EnableNormalDisplay(normal);
+		rt.TraceRay(&camera, &image);
+		if (rgba8_out) memcpy(rgba8_out, image.m_data, image.m_dataSizeInByte);
+		if (ppm_dir) { image.m_outputDir = ppm_dir; image.Output(); }
+		rt.OnDestroy();
+		world.DeconstructWorld();
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+}

