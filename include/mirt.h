@@ -113,6 +113,7 @@ typedef struct mirt_stats {
     double   first_ms;           /* with time_launches=1: same for the depth-0 launches     */
     uint32_t extend_launches;    /* depth>=1 launches timed into extend_ms                 */
     uint32_t first_launches;
+    double   depth_ms[64];       /* with time_launches=1: launch time per bounce index      */
 } mirt_stats;
 
 typedef struct mirt_ctx mirt_ctx;
@@ -123,7 +124,8 @@ int         mirt_create(int device_id, mirt_ctx **out);
 void        mirt_destroy(mirt_ctx *ctx);                 /* HomemadeRayTracer::OnDestroy      */
 const char *mirt_last_error(const mirt_ctx *ctx);        /* ctx may be NULL: last create error */
 int         mirt_device_count(void);
-/* option names: "max_paths" (ray-queue capacity, default 32Mi paths); "time_launches" (0/1:
+/* option names: "max_paths" (ray-queue capacity, default 256Mi paths;
+ * queues are sized by the render at hand, up to this); "time_launches" (0/1:
  * bracket every bounce-kernel launch with HIP events and report the sums in mirt_stats) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 

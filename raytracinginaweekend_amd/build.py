@@ -4,6 +4,8 @@
 
 hipcc cross-compiles without a GPU.  -ffp-contract=off is required: parity with the reference's
 non-FMA SSE2 arithmetic (and with the CPU oracle) is bit-exact only without contraction.
+-fno-slp-vectorize: on gfx950 v_pk_add_f32 / v_pk_mul_f32 issue at ~1/3 the rate of the plain forms
+(tools/ubench/valu_rate.hip: 20 vs 60 T wave-lane-instr/s), so SLP-packing scalar fp32 math loses.
 """
 import os
 import subprocess
@@ -15,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmirt.so")
 SOURCES = ["mirt.hip"]
 DEPS = ["mirt.hip", "rt_kernels.h", "rt_device.h", "scene_host.h", os.path.join("..", "..", "include", "mirt.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
          "-Wall", "-Wno-unused-function"]
 
 
@@ -28,6 +30,7 @@ def stale() -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not stale():
+        build_host(False)
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -35,7 +38,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    build_host(verbose)
     return LIB
+
+
+def build_host(verbose: bool = True) -> None:
+    """The drop-in C++ host layer (g++, no GPU code); its structs embed mirt.h types, so it follows libmirt."""
+    subprocess.run(["make", "-C", os.path.join(HERE, "host")] + ([] if verbose else ["-s"]), check=True)
 
 
 if __name__ == "__main__":

@@ -55,7 +55,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("depth_hist", C.c_uint64 * 64),
                 ("device_ms", C.c_double), ("extend_ms", C.c_double), ("bounce_launches", C.c_uint32),
                 ("batches", C.c_uint32), ("first_ms", C.c_double), ("extend_launches", C.c_uint32),
-                ("first_launches", C.c_uint32)]
+                ("first_launches", C.c_uint32), ("depth_ms", C.c_double * 64)]
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4"),
@@ -80,10 +80,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MirtError(f"{LIB_PATH} is missing: build it with `python -m raytracinginaweekend_amd.build` "
+    path = os.environ.get("MIRT_LIB", LIB_PATH)       # MIRT_LIB: a diagnostic build of the same library (tools/)
+    if not os.path.exists(path):
+        raise MirtError(f"{path} is missing: build it with `python -m raytracinginaweekend_amd.build` "
                         "(the path tracer has no CPU fallback)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp = C.c_void_p
     lib.mirt_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.mirt_destroy.argtypes = [vp]; lib.mirt_destroy.restype = None

@@ -40,9 +40,10 @@ struct mirt_ctx {
     bool prims_in_lds = false;
     mirt_camera cam{};
     DevBuf d_prims, d_nodes, d_objs, d_mats;
-    DevBuf d_queues, d_rad, d_counts, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
-    uint64_t max_paths = 32ull << 20;
+    DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
+    uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 12.1 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
+    uint32_t blocks_per_cu = 8;
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
@@ -89,7 +90,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -108,6 +109,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
         return MIRT_OK;
     }
     if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
+    if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
 }
 
@@ -248,24 +250,42 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const uint32_t n_pix_tiles = (uint32_t)((npix_total + npix_b - 1) / npix_b);
     const uint32_t n_s_tiles = (spp_count + S - 1) / S;
     const uint32_t n_batches = n_pix_tiles * n_s_tiles;
-    const uint32_t n_depth = p->max_depth + 2;            // counts[d] = paths entering bounce d
+    const uint32_t n_depth = p->max_depth + 2;            // per depth d: [0] slots reserved in, [1] paths entering bounce d
+    const uint32_t max_grid = (uint32_t)c->n_cu * c->blocks_per_cu;
+    // out-queue chunk size (slots a workgroup reserves with one atomic) and the slot capacity that makes an
+    // overflow impossible: a closed chunk holds > chunk-256 paths, every workgroup leaves one open chunk
+    const uint32_t grid_max = (uint32_t)std::min<uint64_t>((capq + MIRT_BLOCK - 1) / MIRT_BLOCK, max_grid);
+    const uint32_t chunk_shift = capq >= (4u << 20) ? 12u : (capq >= (1u << 20) ? 11u : 10u);
+    const uint64_t chunk = 1ull << chunk_shift;
+    const uint64_t n_chunks_max = capq / (chunk - 255) + grid_max + 2;
+    const uint64_t cap_slots = n_chunks_max * chunk;
+    if (cap_slots > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: ray queue larger than 2^32 slots (lower max_paths)");
 
-    if (c->d_queues.ensure(2 * 11 * capq * sizeof(float)) || c->d_rad.ensure(capq * sizeof(float4)) ||
-        c->d_counts.ensure((size_t)n_batches * n_depth * sizeof(uint32_t)))
+    if (c->d_queues.ensure(2 * 11 * cap_slots * sizeof(float)) || c->d_rad.ensure(capq * sizeof(float4)) ||
+        c->d_counts.ensure(((size_t)n_batches * n_depth * 2 + 1) * sizeof(uint32_t)) || c->d_len.ensure(2 * n_chunks_max * sizeof(uint32_t)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the ray queues failed (lower the max_paths option)");
-    PathQ q[2] = { carve_queue((float *)c->d_queues.p, capq), carve_queue((float *)c->d_queues.p + 11 * capq, capq) };
+    PathQ q[2] = { carve_queue((float *)c->d_queues.p, cap_slots), carve_queue((float *)c->d_queues.p + 11 * cap_slots, cap_slots) };
+    uint32_t *qlen[2] = { (uint32_t *)c->d_len.p, (uint32_t *)c->d_len.p + n_chunks_max };
     uint32_t *counts = (uint32_t *)c->d_counts.p;
-    HIPCHK(c, hipMemsetAsync(counts, 0, (size_t)n_batches * n_depth * sizeof(uint32_t), st));
+    const size_t n_counts = (size_t)n_batches * n_depth * 2 + 1;
+    uint32_t *overflow = counts + n_counts - 1;
+    HIPCHK(c, hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), st));
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
 
     BounceArgs a{};
     a.sc = c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
-    const uint32_t max_grid = (uint32_t)c->n_cu * 8u;
+#ifdef MIRT_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) HIPCHK(c, hipMalloc(&d_stamps, 16 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), st));
+    a.stamps = d_stamps;
+#endif
+    a.chunk_shift = chunk_shift; a.cap_slots = (uint32_t)cap_slots; a.overflow = overflow;
     uint32_t launches = 0, batch = 0;
     const bool timed = stats && c->time_launches;
-    std::vector<uint8_t> ev_first;       // per timed launch: 1 = depth 0
+    std::vector<uint8_t> ev_first;       // per timed launch: its depth (clamped to 63)
     if (timed) {
         size_t need = 2 * (size_t)n_batches * (p->max_depth + 1);
         while (c->ev_pool.size() < need) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
@@ -277,17 +297,18 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
             const uint32_t s0 = spp_begin + stile * S;
             const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
             const uint32_t n_first = np * ns;
-            uint32_t *cnt = counts + (size_t)batch * n_depth;
+            uint32_t *cnt = counts + (size_t)batch * n_depth * 2;
             a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_first = n_first;
             const uint32_t grid = std::min<uint32_t>((n_first + MIRT_BLOCK - 1) / MIRT_BLOCK, max_grid);
             for (uint32_t d = 0; d <= p->max_depth; ++d) {
                 a.depth = d;
                 a.in = q[d & 1]; a.out = q[(d + 1) & 1];
-                a.count_in = cnt + d; a.count_out = cnt + d + 1;
+                a.res_in = cnt + 2 * d; a.res_out = cnt + 2 * (d + 1); a.alive_out = cnt + 2 * (d + 1) + 1;
+                a.len_in = qlen[d & 1]; a.len_out = qlen[(d + 1) & 1];
                 if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size()], st));
                 if (d == 0) launch_bounce<true>(c, list, a, grid, st);
                 else launch_bounce<false>(c, list, a, grid, st);
-                if (timed) { HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size() + 1], st)); ev_first.push_back(d == 0); }
+                if (timed) { HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size() + 1], st)); ev_first.push_back((uint8_t)std::min<uint32_t>(d, 63u)); }
                 ++launches;
                 if (p->flags & MIRT_FLAG_NORMAL_DISPLAY) break;      // every path ends at its first vertex
             }
@@ -300,19 +321,31 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
         HIPCHK(c, hipEventRecord(c->ev1, st));
         HIPCHK(c, hipStreamSynchronize(st));
         float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        std::vector<uint32_t> h((size_t)n_batches * n_depth);
+        std::vector<uint32_t> h(n_counts);
         HIPCHK(c, hipMemcpy(h.data(), counts, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (h[n_counts - 1]) return fail(c, MIRT_ERR_STATE, "mirt_render_device: ray-queue reservation overflowed (internal bound violated)");
         stats->device_ms = ms; stats->bounce_launches = launches; stats->batches = n_batches;
         for (size_t i = 0; i < ev_first.size(); ++i) {
             float t = 0; HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[2 * i], c->ev_pool[2 * i + 1]));
-            if (ev_first[i]) { stats->first_ms += t; stats->first_launches++; } else { stats->extend_ms += t; stats->extend_launches++; }
+            stats->depth_ms[ev_first[i]] += t;
+            if (ev_first[i] == 0) { stats->first_ms += t; stats->first_launches++; } else { stats->extend_ms += t; stats->extend_launches++; }
         }
+#ifdef MIRT_STAMPS
+        {
+            unsigned long long hs[16];
+            HIPCHK(c, hipMemcpy(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost));
+            static const char *nm[8] = { "load+wait", "extend+classify", "coop draws", "finish+rad store", "barrier A", "atomic+barrier B", "queue store+barrier C", "loop overhead" };
+            unsigned long long tot = 0; for (int k = 0; k < 8; ++k) tot += hs[k];
+            fprintf(stderr, "[stamps] waves %llu, cycles/wave %.0f\n", hs[8], hs[8] ? (double)tot / hs[8] : 0.0);
+            for (int k = 0; k < 8; ++k) fprintf(stderr, "[stamps] %-22s %6.2f %%\n", nm[k], tot ? 100.0 * hs[k] / tot : 0.0);
+        }
+#endif
         stats->samples = npix_total * spp_count;
         stats->rays = stats->samples;                                  // bounce 0 traces one ray per sample
         stats->depth_hist[0] = stats->samples;
         for (uint32_t b = 0; b < n_batches; ++b)
             for (uint32_t d = 1; d <= p->max_depth; ++d) {
-                uint64_t v = h[(size_t)b * n_depth + d];
+                uint64_t v = h[((size_t)b * n_depth + d) * 2 + 1];
                 stats->rays += v; stats->depth_hist[d < 63 ? d : 63] += v;
             }
     }

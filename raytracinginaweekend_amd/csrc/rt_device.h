@@ -298,10 +298,25 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx)
 }
 
 // ----------------------------------------------------------------------------- Materials.cpp
+// Scatter is split in three so the render kernel can draw for a whole wavefront at once:
+//   scatter_need   what the material wants from the RNG (nothing / a unit-sphere point / one unorm)
+//   (the draws)    per lane in the function-level hooks, wave-cooperative in k_bounce
+//   scatter_finish the rest of Scatter, given the draws
 struct Scat { bool alive; f3 atten, dir, emitted; };
+enum { NEED_NONE = 0, NEED_SPHERE = 1, NEED_UNORM = 2 };
 
-template <class M, class G>
-__device__ __forceinline__ void scatter(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, G &g, Scat &o)
+// lazy: with a stateless keyed source an absorbed Lambertian path (Materials.cpp:32 decides
+// independently of the draw) skips its draws; the explicit-stream hooks never skip.
+__device__ __forceinline__ uint32_t scatter_need(uint32_t kind, f3 dir_in, f3 nrm, bool lazy)
+{
+    if (kind == MIRT_MAT_LAMBERTIAN) return (lazy && !(dot(dir_in, nrm) < 0)) ? NEED_NONE : NEED_SPHERE;
+    if (kind == MIRT_MAT_METAL) return NEED_SPHERE;
+    if (kind == MIRT_MAT_DIELECTRIC) return NEED_UNORM;
+    return NEED_NONE;
+}
+
+template <class M>
+__device__ __forceinline__ void scatter_finish(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
 {
     o.emitted = mk(0.0f, 0.0f, 0.0f);                                   // HomemadeRayTracer.cpp:173
     o.atten = mk(0.0f, 0.0f, 0.0f);
@@ -310,31 +325,43 @@ __device__ __forceinline__ void scatter(const M &m, f3 dir_in, const f3 &pos, co
     if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
         o.alive = dot(dir_in, nrm) < 0;
         o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-        if (G::lazy && !o.alive) return;
-        f3 target = (pos + nrm) + in_unit_sphere(g);
+        f3 target = (pos + nrm) + sphere_pt;
         o.dir = target - pos;
-    } else if (kind == MIRT_MAT_METAL) {                                // Materials.cpp:99-106
-        f3 refl = reflect(normalize(dir_in), nrm);
-        o.dir = refl + scale(in_unit_sphere(g), m.fuzz);
-        o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
-        o.alive = dot(o.dir, nrm) > 0;
-    } else if (kind == MIRT_MAT_DIELECTRIC) {                           // Materials.cpp:172-217
-        float ior = m.ior;
-        f3 uv = normalize(dir_in), outward, refracted = mk(0.0f, 0.0f, 0.0f);
-        float ni_over_nt, cosine, reflect_prob;
-        o.atten = mk(1.0f, 1.0f, 1.0f);
-        float dn = dot(uv, nrm);
-        if (dn > 0) { outward = neg(nrm); ni_over_nt = ior; cosine = ior * dn; }
-        else { outward = nrm; ni_over_nt = 1.0f / ior; cosine = -dn; }
-        if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ior);
-        else reflect_prob = 1.0f;
-        if (scatter_unorm(g) < reflect_prob) o.dir = reflect(uv, nrm);
-        else o.dir = refracted;
-        o.alive = true;
+    } else if (kind == MIRT_MAT_METAL || kind == MIRT_MAT_DIELECTRIC) {
+        f3 uv = normalize(dir_in);                                      // shared by both (Materials.cpp:102,175)
+        f3 refl = reflect(uv, nrm);                                     // Materials.cpp:102,209
+        if (kind == MIRT_MAT_METAL) {                                   // Materials.cpp:99-106
+            o.dir = refl + scale(sphere_pt, m.fuzz);
+            o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+            o.alive = dot(o.dir, nrm) > 0;
+        } else {                                                        // Materials.cpp:172-217
+            float ior = m.ior;
+            f3 outward, refracted = mk(0.0f, 0.0f, 0.0f);
+            float ni_over_nt, cosine, reflect_prob;
+            o.atten = mk(1.0f, 1.0f, 1.0f);
+            float dn = dot(uv, nrm);
+            if (dn > 0) { outward = neg(nrm); ni_over_nt = ior; cosine = ior * dn; }
+            else { outward = nrm; ni_over_nt = 1.0f / ior; cosine = -dn; }
+            if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ior);
+            else reflect_prob = 1.0f;
+            o.dir = (unorm < reflect_prob) ? refl : refracted;
+            o.alive = true;
+        }
     } else {                                                            // DiffuseLight, Materials.cpp:260-264
         o.emitted = mk(m.emit[0], m.emit[1], m.emit[2]);
         o.alive = false;
     }
+}
+
+// one lane, draws in the reference's call order
+template <class M, class G>
+__device__ __forceinline__ void scatter(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, G &g, Scat &o)
+{
+    uint32_t need = scatter_need(m.kind, dir_in, nrm, G::lazy);
+    f3 sp = mk(0.0f, 0.0f, 0.0f); float u = 0.0f;
+    if (need == NEED_SPHERE) sp = in_unit_sphere(g);
+    else if (need == NEED_UNORM) u = scatter_unorm(g);
+    scatter_finish(m, dir_in, pos, nrm, sp, u, o);
 }
 
 // ----------------------------------------------------------------------------- SimpleCamera.cpp:55-60

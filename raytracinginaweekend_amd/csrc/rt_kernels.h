@@ -42,15 +42,40 @@ struct SceneDev {
 
 struct BounceArgs {
     PathQ in, out;
-    const uint32_t *count_in;
-    uint32_t *count_out;
+    // Queues are reserved in chunks of 1 << chunk_shift slots: a workgroup takes a chunk from the
+    // out-queue with ONE atomic and packs the survivors of its successive tiles into it, so the
+    // reservation counter sees one atomic per ~chunk/256 tiles instead of one per tile (a single
+    // word serves only ~90 M returning atomics/s, which capped the first version of this kernel).
+    // len[c] = slots of chunk c that hold paths; the unused tail of a chunk is skipped by the reader.
+    const uint32_t *res_in;        // slots reserved in the in-queue (multiple of the chunk size)
+    const uint32_t *len_in;
+    uint32_t *res_out;
+    uint32_t *len_out;
+    uint32_t *alive_out;           // paths written to the out-queue (statistics: rays of the next depth)
+    uint32_t *overflow;            // set if a reservation would pass cap_slots (never, by the host's bound)
+    uint32_t chunk_shift, cap_slots;
     uint32_t n_first;
     float4 *rad;
     SceneDev sc;
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
     uint32_t depth, max_depth, flags, k0, k1;
+#ifdef MIRT_STAMPS
+    unsigned long long *stamps;   // diagnostic build only: per-segment wave-cycle sums (see tools/)
+#endif
 };
+
+#ifdef MIRT_STAMPS
+#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define STAMP(k) do { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
+#define STAMP_FLUSH do { if (lane == 0 && a.stamps) { for (int k_ = 0; k_ < 8; ++k_) atomicAdd(a.stamps + k_, st_acc[k_]); atomicAdd(a.stamps + 8, 1ull); } } while (0)
+#define STAMP_VMWAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#define STAMP_VMWAIT
+#endif
 
 // ---------------------------------------------------------------------------------- LDS staging
 struct LdsView {
@@ -154,14 +179,84 @@ __device__ __forceinline__ void generate_ray(const BounceArgs &a, uint32_t pixel
         u = ((float)i + map_unorm(r[0])) / (float)a.width;
         v = ((float)j + map_unorm(r[1])) / (float)a.height;
     }
-    // RandomInUnitDisk: iteration 0 = block 0 lanes 2,3; iterations 2k-1, 2k = block k
-    f3 p = mk(map_pm1(r[2]), map_pm1(r[3]), 0.0f);
-    for (uint32_t it = 1; it < MIRT_REJECT_CAP && dot(p, p) >= 1.0f; ++it) {
-        uint32_t k = 2u + 2u * it;
-        if ((k & 3u) == 0u) g.block(k >> 2, r);
-        p = mk(map_pm1(r[k & 3u]), map_pm1(r[(k & 3u) + 1u]), 0.0f);
+    // RandomInUnitDisk: iteration 0 = block 0 lanes 2,3; iterations 2k-1, 2k = block k.  With a pinhole
+    // (lens radius 0, wave-uniform) the disk point is multiplied by 0 (SimpleCamera.cpp:57) and the keyed
+    // stream has no state to advance, so the loop is skipped; offset is then +-0 either way.
+    f3 p = mk(0.0f, 0.0f, 0.0f);
+    if (a.cam.lens_radius != 0.0f) {
+        p = mk(map_pm1(r[2]), map_pm1(r[3]), 0.0f);
+        for (uint32_t it = 1; it < MIRT_REJECT_CAP && dot(p, p) >= 1.0f; ++it) {
+            uint32_t k = 2u + 2u * it;
+            if ((k & 3u) == 0u) g.block(k >> 2, r);
+            p = mk(map_pm1(r[k & 3u]), map_pm1(r[(k & 3u) + 1u]), 0.0f);
+        }
     }
     camera_ray(a.cam, u, v, p, o, d);
+}
+
+// ---------------------------------------------------------------------------------- wave-cooperative draws
+// Rejection sampling of the unit sphere (Randomizer.h:40-48) accepts 52 % of its candidates, so a wave
+// whose lanes each loop "until mine is accepted" runs ~6 rounds with a third of its lanes working.
+// The draws are keyed (pixel, sample, stage, iteration) and any lane can evaluate any key, so after
+// round 0 the still-pending lanes publish their keys in LDS and ALL 64 lanes evaluate candidates for
+// them: with n pending, each gets G = pow2 <= 64/n consecutive iterations in one round.  The owner
+// takes the first accepted iteration, exactly the one its own loop would have stopped at.
+struct CoopLds { uint32_t pix[64], smp[64], it[64]; };
+
+__device__ __forceinline__ f3 sphere_candidate(uint32_t pixel, uint32_t sample, uint32_t stage, uint32_t it, uint32_t k0, uint32_t k1)
+{
+    uint32_t r[4];
+    philox4x32_10(pixel, sample, stage, it, k0, k1, r);
+    return mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
+}
+
+// need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this)
+__device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t need, uint32_t pixel, uint32_t sample,
+                                           uint32_t stage, uint32_t k0, uint32_t k1, f3 &sphere_pt, float &unorm)
+{
+    bool pending = false;
+    uint32_t next_it = 1;
+    if (need != NEED_NONE) {                                    // round 0: block 0 serves all three materials
+        uint32_t r[4];
+        philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
+        unorm = map_unorm(r[0]);
+        if (need == NEED_SPHERE) {
+            sphere_pt = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
+            pending = dot(sphere_pt, sphere_pt) >= 1.0f;
+        }
+    }
+    unsigned long long mask;
+    while ((mask = __ballot(pending)) != 0ull) {
+        const uint32_t n = (uint32_t)__popcll(mask);
+        const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per pending lane
+        const uint32_t G = 1u << lg;
+        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (pending) { cl.pix[rank] = pixel; cl.smp[rank] = sample; cl.it[rank] = next_it; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t e = lane >> lg, sub = lane & (G - 1u);
+        f3 c = mk(0.0f, 0.0f, 0.0f);
+        bool acc = false;
+        if (e < n) {
+            uint32_t it = cl.it[e] + sub;
+            if (it < MIRT_REJECT_CAP) {
+                c = sphere_candidate(cl.pix[e], cl.smp[e], stage, it, k0, k1);
+                acc = !(dot(c, c) >= 1.0f) || it == MIRT_REJECT_CAP - 1u;        // the cap keeps its last candidate, like the per-lane loop
+            }
+        }
+        const unsigned long long am = __ballot(acc);
+        uint32_t src = lane;
+        bool got = false;
+        if (pending) {
+            uint32_t bits = (uint32_t)(am >> (rank << lg)) & ((1u << G) - 1u);     // this lane's G helpers, lowest = earliest iteration
+            if (bits) { src = (rank << lg) + (uint32_t)__builtin_ctz(bits); got = true; }
+            else next_it += G;
+        }
+        float cx = __shfl(c.x, (int)src), cy = __shfl(c.y, (int)src), cz = __shfl(c.z, (int)src);
+        if (got) { sphere_pt = mk(cx, cy, cz); pending = false; }
+        __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
+    }
 }
 
 // ---------------------------------------------------------------------------------- the bounce kernel
@@ -169,18 +264,31 @@ template <bool FIRST, int ACCEL /*0 list, 1 bvh*/, bool PLDS>
 __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ uint32_t s_wcnt[MIRT_BLOCK / 64];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wcnt[2][MIRT_BLOCK / 64];   // double-buffered by iteration parity: no third barrier
+    __shared__ uint32_t s_base[2];
+    __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
 
-    const uint32_t n_in = FIRST ? a.n_first : *a.count_in;
+    const uint32_t n_in = FIRST ? a.n_first : *a.res_in;
     if (blockIdx.x * MIRT_BLOCK >= n_in) return;
     const LdsView lv = lds_view(a.sc, smem);
     lds_stage(a.sc, lv);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t chunk = 1u << a.chunk_shift;
+    // thread 0's view of the workgroup's open out-chunk [ck_base, ck_base + chunk), filled up to ck_next
+    uint32_t ck_base = 0xFFFFFFFFu, ck_next = 0, blk_alive = 0, par = 0;
+    STAMP_DECL;
 
     for (uint32_t base = blockIdx.x * MIRT_BLOCK; base < n_in; base += gridDim.x * MIRT_BLOCK) {
+        STAMP(7);
         const uint32_t idx = base + threadIdx.x;
-        const bool active = idx < n_in;
+        bool active;
+        if (FIRST) active = idx < n_in;
+        else {
+            const uint32_t len = a.len_in[base >> a.chunk_shift];           // wave-uniform
+            const uint32_t in_chunk = base & (chunk - 1u);
+            if (in_chunk >= len) continue;                                      // unused tail of a chunk (uniform)
+            active = in_chunk + threadIdx.x < len;
+        }
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
         uint32_t pixel = 0, sample = 0;
         if (active) {
@@ -195,63 +303,94 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
                 pixel = a.in.pix[idx]; sample = a.in.smp[idx];
             }
         }
-        bool alive = false;
-        f3 no = o, nd = d;
+        STAMP_VMWAIT; STAMP(0);
+        // -------- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
+        bool done = false;                    // path ends at this vertex with `radiance`
+        f3 radiance = mk(0.0f, 0.0f, 0.0f);
+        uint32_t need = NEED_NONE;
+        Hit h; h.pos = o; h.nrm = d; h.mat = 0;
+        const MatRec *M = a.sc.mats;
         if (active) {
-            // -------- extend: HomemadeRayTracer.cpp:160-162
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
             int32_t best = ACCEL ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max)
                                  : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max);
-            // -------- shade: HomemadeRayTracer.cpp:163-187, forward (throughput) order
-            f3 radiance;
-            if (best < 0) {
-                radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]);
+            if (best < 0) {                                                        // :186
+                radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
             } else {
-                Hit h;
                 const PrimRec *P = PLDS ? lv.prims : a.sc.prims;
                 prim_record(P[best], best, o, d, t_max, false, h);
-                if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {
-                    radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f);
-                } else if (!(a.depth < a.max_depth)) {
-                    radiance = mk(0.0f, 0.0f, 0.0f);          // Scatter not called: emitted stays zero (:173-174)
+                if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
+                    radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done = true;
+                } else if (!(a.depth < a.max_depth)) {                             // Scatter not called: emitted stays zero (:173-174)
+                    done = true;
                 } else {
-                    const MatRec *M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
-                    PhiloxKeyed g; g.pixel = pixel; g.sample = sample; g.stage = 1u + a.depth; g.k0 = a.k0; g.k1 = a.k1;
-                    Scat s;
-                    scatter(*M, d, h.pos, h.nrm, g, s);
-                    if (s.alive) { alive = true; no = h.pos; nd = s.dir; thr = thr * s.atten; }
-                    else radiance = thr * s.emitted;
+                    M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
+                    need = scatter_need(M->kind, d, h.nrm, true);
                 }
             }
-            if (!alive) {
-                uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
-                a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-            }
         }
-        // -------- compaction: wave ballot + prefix popcount, one atomic per workgroup
+        STAMP(1);
+        // -------- phase 2 (whole wave): the draws of Scatter
+        f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
+        coop_draws(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
+        STAMP(2);
+        // -------- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
+        bool alive = false;
+        f3 no = o, nd = d;
+        if (active && !done) {
+            Scat s;
+            scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
+            if (s.alive) { alive = true; no = h.pos; nd = s.dir; thr = thr * s.atten; }
+            else { radiance = thr * s.emitted; done = true; }
+        }
+        if (active && done) {
+            uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
+            a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        }
+        STAMP(3);
+        // -------- compaction: wave ballot + prefix popcount; slots come from the workgroup's open chunk
         const unsigned long long m = __ballot(alive);
         const uint32_t wcnt = (uint32_t)__popcll(m);
         const uint32_t wpre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wcnt[wave] = wcnt;
+        if (lane == 0) s_wcnt[par][wave] = wcnt;
         __syncthreads();
+        STAMP(4);
         if (threadIdx.x == 0) {
             uint32_t tot = 0;
 #pragma unroll
-            for (int w = 0; w < MIRT_BLOCK / 64; ++w) tot += s_wcnt[w];
-            s_base = tot ? atomicAdd(a.count_out, tot) : 0u;
+            for (int w = 0; w < MIRT_BLOCK / 64; ++w) tot += s_wcnt[par][w];
+            uint32_t at = 0xFFFFFFFFu;
+            if (tot) {
+                if (ck_base == 0xFFFFFFFFu || ck_next + tot > ck_base + chunk) {
+                    if (ck_base != 0xFFFFFFFFu) a.len_out[ck_base >> a.chunk_shift] = ck_next - ck_base;   // close
+                    uint32_t nb = atomicAdd(a.res_out, chunk);
+                    if (nb + chunk > a.cap_slots) { atomicOr(a.overflow, 1u); ck_base = 0xFFFFFFFFu; }
+                    else { ck_base = nb; ck_next = nb; }
+                }
+                if (ck_base != 0xFFFFFFFFu) { at = ck_next; ck_next += tot; blk_alive += tot; }
+            }
+            s_base[par] = at;
         }
         __syncthreads();
-        if (alive) {
-            uint32_t pos = s_base + wpre;
-            for (uint32_t w = 0; w < wave; ++w) pos += s_wcnt[w];
+        STAMP(5);
+        const uint32_t sb = s_base[par];
+        if (alive && sb != 0xFFFFFFFFu) {
+            uint32_t pos = sb + wpre;
+            for (uint32_t w = 0; w < wave; ++w) pos += s_wcnt[par][w];
             a.out.ox[pos] = no.x; a.out.oy[pos] = no.y; a.out.oz[pos] = no.z;
             a.out.dx[pos] = nd.x; a.out.dy[pos] = nd.y; a.out.dz[pos] = nd.z;
             a.out.tr[pos] = thr.x; a.out.tg[pos] = thr.y; a.out.tb[pos] = thr.z;
             a.out.pix[pos] = pixel; a.out.smp[pos] = sample;
         }
-        __syncthreads();   // s_wcnt / s_base are rewritten by the next iteration
+        par ^= 1u;                             // flips only on executed iterations (the skip above has no barriers)
+        STAMP(6);
     }
+    if (threadIdx.x == 0) {
+        if (ck_base != 0xFFFFFFFFu) a.len_out[ck_base >> a.chunk_shift] = ck_next - ck_base;
+        if (blk_alive) atomicAdd(a.alive_out, blk_alive);
+    }
+    STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------------- accumulate

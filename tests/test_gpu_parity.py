@@ -165,7 +165,7 @@ def test_batching_and_ranges(gpu, orc):
     a = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
     gpu.set_option("max_paths", 3 * w * h + 17)                  # sample tiles of 3
     b = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
-    gpu.set_option("max_paths", 32 << 20)
+    gpu.set_option("max_paths", 256 << 20)
     H.assert_bits(a["sum"], ref["sum"], "pixel tiles"); H.assert_bits(b["sum"], ref["sum"], "sample tiles")
     osum, _ = orc.trace(s, cam, w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
     H.assert_bits(ref["sum"], osum, "vs oracle")
