@@ -41,7 +41,7 @@ struct mirt_ctx {
     mirt_camera cam{};
     DevBuf d_prims, d_nodes, d_objs, d_mats;
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
-    uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 12.1 GB queues + 4.3 GB radiance slots when fully used
+    uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
     uint32_t blocks_per_cu = 8;
     std::vector<hipEvent_t> ev_pool;
@@ -215,12 +215,10 @@ static void launch_bounce(const mirt_ctx *c, bool list, const BounceArgs &a, uin
     }
 }
 
-static PathQ carve_queue(float *base, size_t cap)
+static PathQ carve_queue(float4 *base, size_t cap)
 {
     PathQ q;
-    q.ox = base; q.oy = base + cap; q.oz = base + 2 * cap; q.dx = base + 3 * cap; q.dy = base + 4 * cap; q.dz = base + 5 * cap;
-    q.tr = base + 6 * cap; q.tg = base + 7 * cap; q.tb = base + 8 * cap;
-    q.pix = (uint32_t *)(base + 9 * cap); q.smp = (uint32_t *)(base + 10 * cap);
+    q.p0 = base; q.p1 = base + cap; q.p2 = base + 2 * cap;
     return q;
 }
 
@@ -261,10 +259,10 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const uint64_t cap_slots = n_chunks_max * chunk;
     if (cap_slots > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: ray queue larger than 2^32 slots (lower max_paths)");
 
-    if (c->d_queues.ensure(2 * 11 * cap_slots * sizeof(float)) || c->d_rad.ensure(capq * sizeof(float4)) ||
+    if (c->d_queues.ensure(2 * 3 * cap_slots * sizeof(float4)) || c->d_rad.ensure(capq * sizeof(float4)) ||
         c->d_counts.ensure(((size_t)n_batches * n_depth * 2 + 1) * sizeof(uint32_t)) || c->d_len.ensure(2 * n_chunks_max * sizeof(uint32_t)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the ray queues failed (lower the max_paths option)");
-    PathQ q[2] = { carve_queue((float *)c->d_queues.p, cap_slots), carve_queue((float *)c->d_queues.p + 11 * cap_slots, cap_slots) };
+    PathQ q[2] = { carve_queue((float4 *)c->d_queues.p, cap_slots), carve_queue((float4 *)c->d_queues.p + 3 * cap_slots, cap_slots) };
     uint32_t *qlen[2] = { (uint32_t *)c->d_len.p, (uint32_t *)c->d_len.p + n_chunks_max };
     uint32_t *counts = (uint32_t *)c->d_counts.p;
     const size_t n_counts = (size_t)n_batches * n_depth * 2 + 1;

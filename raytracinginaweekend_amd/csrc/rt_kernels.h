@@ -14,9 +14,10 @@
 // `col += Sample(r, 0)` loop (HomemadeRayTracer.cpp:126-133).  No float atomics, no run-to-run
 // variation.
 //
-// Live paths are kept dense: each bounce reads queue `in` (SoA: origin, direction, throughput,
-// pixel, sample; lane i reads element base+i of every array, fully coalesced) and the survivors
-// are appended to queue `out` with a wave ballot + prefix popcount, one atomic per workgroup.
+// Live paths are kept dense: each bounce reads queue `in` (three float4 planes per slot: origin,
+// direction, throughput, pixel, sample; lane i reads element base+i of each plane, fully coalesced)
+// and the survivors are appended to queue `out` with a wave ballot + prefix popcount; output slots
+// come from chunks a workgroup reserves with one atomic per ~16 tiles.
 #pragma once
 #include "rt_device.h"
 
@@ -24,9 +25,10 @@ namespace mirt {
 
 #define MIRT_BLOCK 256
 
+// A path queue: three planes of float4 per slot -- (ox,oy,oz,dx) (dy,dz,tr,tg) (tb,pixel,sample,-) -- so a
+// path moves with three 16-byte accesses per lane, each perfectly coalesced (lane i at base + 16*i).
 struct PathQ {
-    float *ox, *oy, *oz, *dx, *dy, *dz, *tr, *tg, *tb;
-    uint32_t *pix, *smp;
+    float4 *p0, *p1, *p2;
 };
 
 struct SceneDev {
@@ -65,6 +67,11 @@ struct BounceArgs {
 #endif
 };
 
+// MIRT_EXP: ablation bits for timing experiments on the depth>=1 kernel (tools/ablate.sh); never set in the product
+#ifndef MIRT_EXP
+#define MIRT_EXP 0
+#endif
+#define EXP_ON(bit) (!FIRST && (MIRT_EXP & (bit)))
 #ifdef MIRT_STAMPS
 #define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
 #define STAMP(k) do { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
@@ -297,10 +304,12 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
                 pixel = a.pix0 + pl; sample = a.spp0 + sl;
                 generate_ray(a, pixel, sample, o, d);
             } else {
-                o = mk(a.in.ox[idx], a.in.oy[idx], a.in.oz[idx]);
-                d = mk(a.in.dx[idx], a.in.dy[idx], a.in.dz[idx]);
-                thr = mk(a.in.tr[idx], a.in.tg[idx], a.in.tb[idx]);
-                pixel = a.in.pix[idx]; sample = a.in.smp[idx];
+                if (EXP_ON(32)) { o = mk(0.1f * lane, 0.0f, 0.5f); d = mk(0.3f, -0.5f + 0.01f * lane, -1.0f); pixel = idx % (a.npix); sample = a.spp0; }
+                else {
+                const float4 q0 = a.in.p0[idx], q1 = a.in.p1[idx], q2 = a.in.p2[idx];
+                o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y); thr = mk(q1.z, q1.w, q2.x);
+                pixel = __float_as_uint(q2.y); sample = __float_as_uint(q2.z);
+                }
             }
         }
         STAMP_VMWAIT; STAMP(0);
@@ -313,7 +322,9 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         if (active) {
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
-            int32_t best = ACCEL ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max)
+            int32_t best;
+            if (EXP_ON(8)) { best = (int32_t)(lane % 9u); t_max = 1.0f + 0.01f * lane; }
+            else best = ACCEL ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max)
                                  : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max);
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
@@ -333,18 +344,20 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         STAMP(1);
         // -------- phase 2 (whole wave): the draws of Scatter
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
-        coop_draws(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
+        if (EXP_ON(2)) { sp = mk(0.1f, 0.2f, 0.3f); un = 0.5f; }
+        else coop_draws(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
         STAMP(2);
         // -------- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         bool alive = false;
         f3 no = o, nd = d;
         if (active && !done) {
             Scat s;
-            scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
+            if (EXP_ON(4)) { s.alive = (lane & 7u) != 0u; s.dir = sp + h.nrm; s.atten = mk(0.5f, 0.5f, 0.5f); s.emitted = mk(0.0f, 0.0f, 0.0f); }
+            else scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { alive = true; no = h.pos; nd = s.dir; thr = thr * s.atten; }
             else { radiance = thr * s.emitted; done = true; }
         }
-        if (active && done) {
+        if (active && done && !EXP_ON(1)) {
             uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
             a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
@@ -375,13 +388,13 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         __syncthreads();
         STAMP(5);
         const uint32_t sb = s_base[par];
-        if (alive && sb != 0xFFFFFFFFu) {
+        if (EXP_ON(16)) asm volatile("" :: "v"(no.x), "v"(no.y), "v"(no.z), "v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(thr.x), "v"(thr.y), "v"(thr.z));
+        if (alive && sb != 0xFFFFFFFFu && !EXP_ON(16)) {
             uint32_t pos = sb + wpre;
             for (uint32_t w = 0; w < wave; ++w) pos += s_wcnt[par][w];
-            a.out.ox[pos] = no.x; a.out.oy[pos] = no.y; a.out.oz[pos] = no.z;
-            a.out.dx[pos] = nd.x; a.out.dy[pos] = nd.y; a.out.dz[pos] = nd.z;
-            a.out.tr[pos] = thr.x; a.out.tg[pos] = thr.y; a.out.tb[pos] = thr.z;
-            a.out.pix[pos] = pixel; a.out.smp[pos] = sample;
+            a.out.p0[pos] = make_float4(no.x, no.y, no.z, nd.x);
+            a.out.p1[pos] = make_float4(nd.y, nd.z, thr.x, thr.y);
+            a.out.p2[pos] = make_float4(thr.z, __uint_as_float(pixel), __uint_as_float(sample), 0.0f);
         }
         par ^= 1u;                             // flips only on executed iterations (the skip above has no barriers)
         STAMP(6);
