@@ -64,9 +64,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     W, H, SPP = args.width, args.height, args.spp
@@ -156,7 +157,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell box 3-ball {W}x{H} @{SPP} spp, depth {args.max_depth}, spp-sharded over {world} GPU(s)",
-                       "seed": args.seed, "accel": "list (9 primitives in LDS)"},
+                       "seed": args.seed, "accel": "list (9 primitives in LDS)", "spp_per_gpu": s_count},
             "mrays_per_s": round(msamples * rays_per_sample, 2), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": roofline, "roofline_other": other,
             "whole_render": {"device_ms_rank0": round(st.device_ms, 3), "first_bounce_ms": round(st.first_ms, 3),

@@ -90,7 +90,11 @@ typedef struct mirt_hit {
 #define MIRT_FLAG_NORMAL_DISPLAY 2u  /* m_enableNormalDisplay, HomemadeRayTracer.cpp:164-167 */
 #define MIRT_FLAG_ACCEL_LIST     4u  /* closest hit by a linear pass over all objects instead
                                         of the BVH (what HitableCombo::Hit does, Hitables.cpp:130-142) */
-#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for tiny scenes, BVH otherwise     */
+#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for tiny scenes, ORDERED otherwise */
+#define MIRT_FLAG_ACCEL_ORDERED  32u /* walk the BVH nearer child first instead of the reference's
+                                        left-then-right order (SimpleObject.cpp:394-402): same closest
+                                        t, far fewer boxes; only the winner of an exact tie can differ.
+                                        No accel flag = the reference's order on the tree as given. */
 
 typedef struct mirt_render_params {
     uint32_t width, height;      /* image->m_width/m_height, HomemadeRayTracer.cpp:100-101 */
@@ -133,6 +137,12 @@ int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 /* Replaces the pointer graph TraceRay walks through World::GetObjectBVHTree()/GetLightSources()
  * (World.h:28,31). */
 int mirt_upload_scene(mirt_ctx *ctx, const mirt_scene *scene);
+/* Host-only, needs no GPU: the library's own BVH builder (binned SAH), the one mirt_upload_scene runs for a
+ * scene without a tree.  The reference's counterpart is the SimpleObjectBVHNode constructor
+ * (SimpleObject.cpp:293-346: random axis, median split, O(N log^2 N) vector copies).  Arrays must hold
+ * capacity_nodes entries (2 * n_objects always suffices); any tree in `scene` is ignored. */
+int mirt_build_bvh(const mirt_scene *scene, uint32_t capacity_nodes, float *node_min, float *node_max,
+                   int32_t *node_left, int32_t *node_right, int32_t *root, uint32_t *n_nodes, uint32_t *depth);
 /* Replaces the `const SimpleCamera*` argument of TraceRay (HomemadeRayTracer.h:22). */
 int mirt_set_camera(mirt_ctx *ctx, const mirt_camera *cam);
 

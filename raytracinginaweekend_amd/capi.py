@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libmirt.so")
 PRIM_SPHERE, PRIM_RECT = 0, 1
 MAT_DIFFUSE_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
 CHILD_NONE = -(1 << 31)
-FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_ACCEL_AUTO = 1, 2, 4, 16
+FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_ACCEL_AUTO, FLAG_ACCEL_ORDERED = 1, 2, 4, 16, 32
 
 f32p = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
@@ -63,7 +63,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", 
 
 EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
-    "mirt_upload_scene", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render",
+    "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
     "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_write_ppm",
 ]
@@ -93,6 +93,7 @@ def load():
     lib.mirt_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mirt_upload_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     lib.mirt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    lib.mirt_build_bvh.argtypes = [C.POINTER(SceneStruct), C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mirt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.mirt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mirt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
@@ -237,6 +238,20 @@ class Context:
         self._ck(self.lib.mirt_arith_batch(self.h, op, _ptr(x), _ptr(yy) if yy is not None else None, x.shape[0], _ptr(out)),
                  "mirt_arith_batch")
         return out
+
+
+def build_bvh(scene):
+    """The library's own (host-side, binned SAH) BVH for `scene`; attaches it to the scene and returns its depth."""
+    st = scene.as_struct()
+    cap = 2 * scene.n_objects + 2
+    mn = np.zeros((cap, 3), np.float32); mx = np.zeros((cap, 3), np.float32)
+    l = np.zeros(cap, np.int32); r = np.zeros(cap, np.int32)
+    root = C.c_int32(); n = C.c_uint32(); depth = C.c_uint32()
+    rc = load().mirt_build_bvh(C.byref(st), cap, _ptr(mn), _ptr(mx), _ptr(l), _ptr(r), C.byref(root), C.byref(n), C.byref(depth))
+    if rc != 0:
+        raise MirtError(f"mirt_build_bvh failed ({rc})")
+    scene.set_bvh(mn[:n.value], mx[:n.value], l[:n.value], r[:n.value], root.value)
+    return depth.value
 
 
 def write_ppm(path, rgba8):

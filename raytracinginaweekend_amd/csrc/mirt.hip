@@ -35,11 +35,12 @@ struct mirt_ctx {
     int device = 0;
     std::string err;
     bool have_scene = false, have_camera = false;
-    SceneDev sc{};
-    uint32_t lds_bytes = 0;
+    SceneDev sc{};                  // LDS plan for the list / reference-order walk (32-byte nodes)
+    SceneDev sc2{};                 // LDS plan for the near-first walk (64-byte nodes)
+    uint32_t lds_bytes = 0, lds_bytes2 = 0;
     bool prims_in_lds = false;
     mirt_camera cam{};
-    DevBuf d_prims, d_nodes, d_objs, d_mats;
+    DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats;
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
@@ -90,7 +91,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -134,14 +135,14 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         r.mat = s->prim_mat[p];
         if (s->prim_kind[p] == MIRT_PRIM_SPHERE) {
             r.info = 0;
-            r.g[0] = g[0]; r.g[1] = 1.f / g[0]; r.g[2] = g[0] * g[0];      // Vec3.h:85-88, Hitables.cpp:23
+            r.ga[0] = g[0]; r.ga[1] = 1.f / g[0]; r.ga[2] = g[0] * g[0];   // Vec3.h:85-88, Hitables.cpp:23
         } else {
             uint32_t ax = s->prim_axes[p];
             const float *q = s->prim_rot + 6 * (size_t)p;
             bool chain = (ax >> 7) & 1, live = false;
             if (chain) for (int k = 0; k < 3; ++k) live |= !(q[2 * k] == 0.0f && q[2 * k + 1] == 1.0f);
             r.info = 1u | ((ax & 3) << 1) | (((ax >> 2) & 3) << 3) | (((ax >> 4) & 3) << 5) | (((ax >> 6) & 1) << 7) | ((live ? 1u : 0u) << 8);
-            for (int i = 0; i < 5; ++i) r.g[i] = g[i];
+            r.ga[0] = g[0]; r.ga[1] = g[1]; r.ga[2] = g[2]; r.gb[0] = g[3]; r.gb[1] = g[4];
             for (int i = 0; i < 6; ++i) r.rot[i] = chain ? q[i] : ((i & 1) ? 1.0f : 0.0f);
         }
     }
@@ -150,8 +151,20 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         for (int a = 0; a < 3; ++a) { nodes[i].mn[a] = tree.box[i].mn[a]; nodes[i].mx[a] = tree.box[i].mx[a]; }
         nodes[i].left = tree.left[i]; nodes[i].right = tree.right[i];
     }
+    std::vector<Node2> nodes2(tree.box.size());
+    for (size_t i = 0; i < nodes2.size(); ++i) {
+        Node2 &n = nodes2[i]; memset(&n, 0, sizeof n);
+        n.left = tree.left[i]; n.right = tree.right[i];
+        auto child_box = [&](int32_t ch) -> host::Box {
+            if (ch == MIRT_CHILD_NONE) { host::Box e; for (int a = 0; a < 3; ++a) { e.mn[a] = 3.402823466e+38f; e.mx[a] = -3.402823466e+38f; } return e; }
+            return ch < 0 ? tree.obox[~ch] : tree.box[ch];
+        };
+        host::Box l = child_box(n.left), r = child_box(n.right);
+        for (int a = 0; a < 3; ++a) { n.lmn[a] = l.mn[a]; n.lmx[a] = l.mx[a]; n.rmn[a] = r.mn[a]; n.rmx[a] = r.mx[a]; }
+    }
     std::vector<uint2> objs(s->n_objects);
-    for (uint32_t o = 0; o < s->n_objects; ++o) objs[o] = make_uint2(s->obj_first[o], s->obj_count[o]);
+    bool single = true;
+    for (uint32_t o = 0; o < s->n_objects; ++o) { objs[o] = make_uint2(s->obj_first[o], s->obj_count[o]); single &= s->obj_count[o] == 1; }
     std::vector<MatRec> mats(s->n_mats);
     for (uint32_t m = 0; m < s->n_mats; ++m) {
         MatRec &r = mats[m]; memset(&r, 0, sizeof r);
@@ -159,16 +172,19 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
     }
     if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
+        c->d_nodes2.ensure(nodes2.size() * sizeof(Node2)) ||
         c->d_objs.ensure(objs.size() * sizeof(uint2)) || c->d_mats.ensure(mats.size() * sizeof(MatRec)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
     HIPCHK(c, hipMemcpy(c->d_prims.p, prims.data(), prims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_nodes2.p, nodes2.data(), nodes2.size() * sizeof(Node2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_objs.p, objs.data(), objs.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_mats.p, mats.data(), mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
 
     SceneDev &d = c->sc;
     d.prims = (const PrimRec *)c->d_prims.p; d.n_prims = s->n_prims;
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
+    d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
     d.root = tree.root;
@@ -180,10 +196,35 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.lds_mats = (s->n_mats * sizeof(MatRec) <= 6u * 1024u) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
     c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 16u * 1024u;
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
-    uint32_t room = used < budget ? (budget - used) / (uint32_t)sizeof(NodeRec) : 0u;
-    d.lds_nodes = std::min<uint32_t>(room, d.n_nodes); used += d.lds_nodes * (uint32_t)sizeof(NodeRec);
-    c->lds_bytes = used;
+    const uint32_t room_bytes = used < budget ? budget - used : 0u;
+    c->sc2 = d;
+    d.node_bytes = (uint32_t)sizeof(NodeRec);
+    d.lds_nodes = std::min<uint32_t>(room_bytes / d.node_bytes, d.n_nodes);
+    c->lds_bytes = used + d.lds_nodes * d.node_bytes;
+    c->sc2.node_bytes = (uint32_t)sizeof(Node2);
+    c->sc2.lds_nodes = std::min<uint32_t>(room_bytes / c->sc2.node_bytes, d.n_nodes);
+    c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
     c->have_scene = true;
+    return MIRT_OK;
+}
+
+// Host-only (no GPU, no context): the library's own BVH builder, the one mirt_upload_scene runs when a scene
+// comes without a tree.  Nodes come out numbered breadth-first, in the node_* format of mirt_scene.
+extern "C" int mirt_build_bvh(const mirt_scene *scene, uint32_t capacity_nodes, float *node_min, float *node_max,
+                              int32_t *node_left, int32_t *node_right, int32_t *root, uint32_t *n_nodes, uint32_t *depth)
+{
+    if (!scene || !node_min || !node_max || !node_left || !node_right || !root || !n_nodes) return MIRT_ERR_ARG;
+    mirt_scene s = *scene; s.n_nodes = 0;
+    if (!host::validate(s).empty()) return MIRT_ERR_ARG;
+    host::Tree tree;
+    if (!host::prepare_tree(s, tree).empty()) return MIRT_ERR_ARG;
+    if (tree.box.size() > capacity_nodes) return MIRT_ERR_NOMEM;
+    for (size_t i = 0; i < tree.box.size(); ++i) {
+        for (int a = 0; a < 3; ++a) { node_min[3 * i + a] = tree.box[i].mn[a]; node_max[3 * i + a] = tree.box[i].mx[a]; }
+        node_left[i] = tree.left[i]; node_right[i] = tree.right[i];
+    }
+    *root = tree.root; *n_nodes = (uint32_t)tree.box.size();
+    if (depth) *depth = tree.depth;
     return MIRT_OK;
 }
 
@@ -195,24 +236,24 @@ extern "C" int mirt_set_camera(mirt_ctx *c, const mirt_camera *cam)
 }
 
 // ------------------------------------------------------------------------------------------ render
-static bool use_list(const mirt_ctx *c, uint32_t flags)
+// 0 = list, 1 = BVH walked in the reference's order, 2 = BVH near-first
+static int accel_mode(const mirt_ctx *c, uint32_t flags)
 {
-    if (flags & MIRT_FLAG_ACCEL_LIST) return true;
-    if (flags & MIRT_FLAG_ACCEL_AUTO) return c->sc.n_prims <= 16 && c->prims_in_lds;
-    return false;
+    if (flags & MIRT_FLAG_ACCEL_LIST) return 0;
+    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 16 && c->prims_in_lds) ? 0 : 2;
+    if (flags & MIRT_FLAG_ACCEL_ORDERED) return 2;
+    return 1;
 }
 
 template <bool FIRST>
-static void launch_bounce(const mirt_ctx *c, bool list, const BounceArgs &a, uint32_t grid, hipStream_t st)
+static void launch_bounce(const mirt_ctx *c, int mode, const BounceArgs &a, uint32_t grid, hipStream_t st)
 {
-    const uint32_t lds = c->lds_bytes;
-    if (list) {
-        if (c->prims_in_lds) hipLaunchKernelGGL((k_bounce<FIRST, 0, true>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
-        else hipLaunchKernelGGL((k_bounce<FIRST, 0, false>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
-    } else {
-        if (c->prims_in_lds) hipLaunchKernelGGL((k_bounce<FIRST, 1, true>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
-        else hipLaunchKernelGGL((k_bounce<FIRST, 1, false>), dim3(grid), dim3(MIRT_BLOCK), lds, st, a);
-    }
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const bool pl = c->prims_in_lds;
+    dim3 g(grid), b(MIRT_BLOCK);
+    if (mode == 0) { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 0, false>), g, b, lds, st, a); }
+    else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 1, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 1, false>), g, b, lds, st, a); }
+    else { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 2, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 2, false>), g, b, lds, st, a); }
 }
 
 static PathQ carve_queue(float4 *base, size_t cap)
@@ -238,7 +279,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     if (spp_count == 0) return MIRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
-    const bool list = use_list(c, p->flags);
+    const int mode = accel_mode(c, p->flags);
 
     // batch geometry: npix_b pixels x S samples <= capacity
     const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
@@ -271,7 +312,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
 
     BounceArgs a{};
-    a.sc = c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
 #ifdef MIRT_STAMPS
@@ -304,8 +345,8 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
                 a.res_in = cnt + 2 * d; a.res_out = cnt + 2 * (d + 1); a.alive_out = cnt + 2 * (d + 1) + 1;
                 a.len_in = qlen[d & 1]; a.len_out = qlen[(d + 1) & 1];
                 if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size()], st));
-                if (d == 0) launch_bounce<true>(c, list, a, grid, st);
-                else launch_bounce<false>(c, list, a, grid, st);
+                if (d == 0) launch_bounce<true>(c, mode, a, grid, st);
+                else launch_bounce<false>(c, mode, a, grid, st);
                 if (timed) { HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size() + 1], st)); ev_first.push_back((uint8_t)std::min<uint32_t>(d, 63u)); }
                 ++launches;
                 if (p->flags & MIRT_FLAG_NORMAL_DISPLAY) break;      // every path ends at its first vertex
@@ -443,14 +484,13 @@ extern "C" int mirt_world_hit_batch(mirt_ctx *c, const float *org, const float *
     mirt_hit *dout = t.up<mirt_hit>(nullptr, nray);
     NEED(dorg && ddir && dout);
     dim3 g((uint32_t)((nray + MIRT_BLOCK - 1) / MIRT_BLOCK)), b(MIRT_BLOCK);
-    const bool list = use_list(c, flags);
-    if (list) {
-        if (c->prims_in_lds) hipLaunchKernelGGL((k_world_hit_batch<0, true>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
-        else hipLaunchKernelGGL((k_world_hit_batch<0, false>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
-    } else {
-        if (c->prims_in_lds) hipLaunchKernelGGL((k_world_hit_batch<1, true>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
-        else hipLaunchKernelGGL((k_world_hit_batch<1, false>), g, b, c->lds_bytes, 0, c->sc, dorg, ddir, (uint32_t)nray, t_min, t_max, dout);
-    }
+    const int mode = accel_mode(c, flags);
+    const bool pl = c->prims_in_lds;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const SceneDev &sd = mode == 2 ? c->sc2 : c->sc;
+    if (mode == 0) { if (pl) hipLaunchKernelGGL((k_world_hit_batch<0, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<0, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
+    else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_world_hit_batch<1, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<1, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
+    else { if (pl) hipLaunchKernelGGL((k_world_hit_batch<2, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<2, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpy(out, dout, nray * sizeof(mirt_hit), hipMemcpyDeviceToHost));
     return MIRT_OK;

@@ -119,12 +119,19 @@ __device__ __forceinline__ float scatter_unorm(StreamDraws &g) { return map_unor
 
 // ----------------------------------------------------------------------------- scene records
 // Device layout (packed from the SoA arrays of mirt_scene at upload):
-struct PrimRec {            // 64 B
+struct PrimRec {            // 64 B; a sphere lives entirely in the first 32 B (one sector per divergent fetch)
     float    off[3];        // TranslatedInstance::m_offset
     uint32_t info;          // bit0 kind, bits1-2 aAxis, 3-4 bAxis, 5-6 cAxis, 7 reverse, 8 rotation active
-    float    g[5];          // sphere: r, 1.f/r, r*r ; rect: a0,a1,b0,b1,c
+    float    ga[3];         // sphere: r, 1.f/r, r*r ; rect: a0,a1,b0
     uint32_t mat;
+    float    gb[2];         // rect: b1,c
     float    rot[6];        // sinx,cosx,siny,cosy,sinz,cosz
+};
+struct Node2 {              // 64 B: both children's boxes in the parent, for near-first traversal
+    float   lmn[3]; int32_t left;
+    float   lmx[3]; int32_t right;
+    float   rmn[3]; uint32_t pad0;
+    float   rmx[3]; uint32_t pad1;
 };
 struct NodeRec {            // 32 B: one aligned 32-byte sector per (per-lane, divergent) node fetch
     float   mn[3]; int32_t left;
@@ -217,7 +224,7 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
     if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
         float a = dot(d, d);
         float b = 2.0f * dot(d, o);
-        float c = dot(o, o) - pr.g[2];
+        float c = dot(o, o) - pr.ga[2];
         float disc = b * b - 4 * a * c;
         if (disc > 0) {
             float sq = __builtin_sqrtf(disc);
@@ -229,11 +236,11 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
         return false;
     }
     uint32_t aA = PI_AAX(info), bA = PI_BAX(info), cA = PI_CAX(info);
-    float t = (pr.g[4] - get(o, cA)) / get(d, cA);
+    float t = (pr.gb[1] - get(o, cA)) / get(d, cA);
     if (t <= t_max && t >= t_min) {
         float a = get(o, aA) + t * get(d, aA);
         float b = get(o, bA) + t * get(d, bA);
-        if (a >= pr.g[0] && a <= pr.g[1] && b >= pr.g[2] && b <= pr.g[3]) { t_out = t; return true; }
+        if (a >= pr.ga[0] && a <= pr.ga[1] && b >= pr.ga[2] && b <= pr.gb[0]) { t_out = t; return true; }
     }
     return false;
 }
@@ -250,7 +257,7 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
     h.t = t; h.mat = (int32_t)pr.mat; h.prim = prim; h.u = 0.0f; h.v = 0.0f;
     h.pos = ray_at(o, d, t);
     if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
-        h.nrm = scale(h.pos, pr.g[1]);                         // (pos - 0) / r == * (1.f/r), Vec3.h:85-88
+        h.nrm = scale(h.pos, pr.ga[1]);                         // (pos - 0) / r == * (1.f/r), Vec3.h:85-88
         if (with_uv) {
             f3 p = normalize(h.pos);
             float theta = atan2f(p.z, p.x);
@@ -264,8 +271,8 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
         if (with_uv) {
             float a = get(o, aA) + t * get(d, aA);
             float b = get(o, bA) + t * get(d, bA);
-            h.u = (a - pr.g[0]) / (pr.g[1] - pr.g[0]);
-            h.v = (b - pr.g[2]) / (pr.g[3] - pr.g[2]);
+            h.u = (a - pr.ga[0]) / (pr.ga[1] - pr.ga[0]);
+            h.v = (b - pr.ga[2]) / (pr.gb[0] - pr.ga[2]);
         }
         h.nrm = mk(0.0f, 0.0f, 0.0f);
         set(h.nrm, cA, PI_REV(info) ? -1.0f : 1.0f);

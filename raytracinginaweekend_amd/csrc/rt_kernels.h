@@ -33,7 +33,10 @@ struct PathQ {
 
 struct SceneDev {
     const PrimRec *prims;  uint32_t n_prims;
-    const NodeRec *nodes;  uint32_t n_nodes;
+    const NodeRec *nodes;  uint32_t n_nodes;     // the tree as given (or built), walked in the reference's order
+    const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
+    uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
+    uint32_t single;                              // every object is one primitive: object index == primitive index
     const uint2   *objs;   uint32_t n_objects;   // (first, count)
     const MatRec  *mats;   uint32_t n_mats;
     int32_t root;
@@ -86,14 +89,14 @@ struct BounceArgs {
 
 // ---------------------------------------------------------------------------------- LDS staging
 struct LdsView {
-    PrimRec *prims; NodeRec *nodes; MatRec *mats; int32_t *stack;
+    PrimRec *prims; unsigned char *nodes; MatRec *mats; int32_t *stack;
 };
 __device__ __forceinline__ LdsView lds_view(const SceneDev &sc, unsigned char *base)
 {
     LdsView v;
     v.prims = (PrimRec *)base;
-    v.nodes = (NodeRec *)(base + sizeof(PrimRec) * sc.lds_prims);
-    v.mats = (MatRec *)((unsigned char *)v.nodes + sizeof(NodeRec) * sc.lds_nodes);
+    v.nodes = base + sizeof(PrimRec) * sc.lds_prims;
+    v.mats = (MatRec *)(v.nodes + sc.node_bytes * sc.lds_nodes);
     v.stack = (int32_t *)((unsigned char *)v.mats + sizeof(MatRec) * sc.lds_mats);
     return v;
 }
@@ -105,7 +108,7 @@ __device__ __forceinline__ void lds_copy16(void *dst, const void *src, uint32_t 
 __device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
 {
     lds_copy16(v.prims, sc.prims, sizeof(PrimRec) * sc.lds_prims);
-    lds_copy16(v.nodes, sc.nodes, sizeof(NodeRec) * sc.lds_nodes);
+    lds_copy16(v.nodes, sc.node_bytes == sizeof(Node2) ? (const void *)sc.nodes2 : (const void *)sc.nodes, sc.node_bytes * sc.lds_nodes);
     lds_copy16(v.mats, sc.mats, sizeof(MatRec) * sc.lds_mats);
     __syncthreads();
 }
@@ -145,7 +148,7 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
     for (;;) {
         if (cur >= 0) {
             NodeRec n;
-            if ((uint32_t)cur < sc.lds_nodes) n = v.nodes[cur];
+            if ((uint32_t)cur < sc.lds_nodes) n = ((const NodeRec *)v.nodes)[cur];
             else {
                 const float4 *g = (const float4 *)(sc.nodes + cur);
                 float4 a = g[0], b = g[1];
@@ -163,6 +166,73 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
                 float t;
                 uint32_t p = ob.x + i;
                 if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+            }
+        }
+        if (sp == 0) break;
+        --sp; cur = stk[sp * MIRT_BLOCK];
+    }
+    return best;
+}
+
+// Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
+// with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
+// current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
+// shrinks early and most of the far subtrees are culled by their box.  The closest t is the same as with
+// the reference's left-first order; only the winner of an exact tie in t can differ.
+__device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, float &t_near)
+{
+#pragma unroll
+    for (uint32_t a = 0; a < 3; ++a) {
+        float id = get(invd, a);
+        float t0 = (mn[a] - get(o, a)) * id;
+        float t1 = (mx[a] - get(o, a)) * id;
+        if (id < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = (t0 > t_min) ? t0 : t_min;
+        t_max = (t1 < t_max) ? t1 : t_max;
+        if (t_max <= t_min) return false;
+    }
+    t_near = t_min;
+    return true;
+}
+
+template <bool PLDS>
+__device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max)
+{
+    int32_t best = -1;
+    int32_t *stk = v.stack + threadIdx.x;
+    uint32_t sp = 0;
+    int32_t cur = sc.root;
+    const PrimRec *P = PLDS ? v.prims : sc.prims;
+    const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
+    for (;;) {
+        if (cur >= 0) {
+            Node2 n;
+            if ((uint32_t)cur < sc.lds_nodes) n = ((const Node2 *)v.nodes)[cur];
+            else {
+                const float4 *g = (const float4 *)(sc.nodes2 + cur);
+                float4 a = g[0], b = g[1], c = g[2], e = g[3];
+                n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
+                n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
+                n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
+            }
+            float tl = 0.0f, tr = 0.0f;
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, tl);
+            const bool hr = n.right != MIRT_CHILD_NONE && slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, tr);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                const int32_t far = left_first ? n.right : n.left;
+                if (sp < sc.stack_depth) { stk[sp * MIRT_BLOCK] = far; ++sp; }
+                cur = left_first ? n.left : n.right;
+                continue;
+            }
+            if (hl) { cur = n.left; continue; }
+            if (hr) { cur = n.right; continue; }
+        } else if (cur != MIRT_CHILD_NONE) {
+            uint32_t first = (uint32_t)~cur, cnt = 1;
+            if (!sc.single) { uint2 ob = sc.objs[~cur]; first = ob.x; cnt = ob.y; }    // Object::Hit, SimpleObject.cpp:73-83
+            for (uint32_t i = 0; i < cnt; ++i) {
+                float t;
+                if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
             }
         }
         if (sp == 0) break;
@@ -267,7 +337,7 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------- the bounce kernel
-template <bool FIRST, int ACCEL /*0 list, 1 bvh*/, bool PLDS>
+template <bool FIRST, int ACCEL /*0 list, 1 bvh walked in the reference's order, 2 bvh near-first*/, bool PLDS>
 __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -324,8 +394,8 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             const float t_min = 0.001f;
             int32_t best;
             if (EXP_ON(8)) { best = (int32_t)(lane % 9u); t_max = 1.0f + 0.01f * lane; }
-            else best = ACCEL ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max)
-                                 : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max);
+            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
+                      : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
             } else {
@@ -489,7 +559,8 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_world_hit_batch(SceneDev sc, con
     if (i >= nray) return;
     f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     float tm = t_max;
-    int32_t best = ACCEL ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm);
+    int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm)
+                 : (ACCEL == 1 ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm));
     Hit h;
     const PrimRec *P = PLDS ? lv.prims : sc.prims;
     if (best >= 0) prim_record(P[best], best, o, d, tm, true, h);

@@ -69,14 +69,24 @@ inline Box object_box(const mirt_scene &s, uint32_t obj)
 struct Tree {
     std::vector<Box> box; std::vector<int32_t> left, right; int32_t root = MIRT_CHILD_NONE;
     uint32_t depth = 0;
+    std::vector<Box> obox;          // object boxes (children of leaves), filled by prepare_tree
 };
 
-// The library's own builder, O(N log N): median split (nth_element) of the object translations on
-// the widest axis of their extent; leaves shaped like the reference's (a node over one or two
-// objects, SimpleObject.cpp:308-322).  Any valid BVH gives the same closest hit.
+// The library's own builder, O(N log N): binned surface-area heuristic over the object boxes (16
+// bins on the widest axis of the centroid bounds, median split on the same axis when the bins do not
+// separate anything or the tree gets deeper than `kSahDepth`, which bounds the traversal stack).
+// Leaves are shaped like the reference's (a node whose children are objects, SimpleObject.cpp:308-322).
+// Any valid BVH yields the same closest t; only the winner of an exact tie depends on the order.
 struct Builder {
+    static constexpr int kBins = 16, kSahDepth = 16;
     const mirt_scene &s; const std::vector<Box> &ob; Tree &t;
-    int32_t build(uint32_t *o, size_t n)
+    static float area(const Box &b)
+    {
+        float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+    float centroid(uint32_t o, int a) const { return 0.5f * (ob[o].mn[a] + ob[o].mx[a]); }
+    int32_t build(uint32_t *o, size_t n, int depth = 0)
     {
         int32_t me = (int32_t)t.box.size();
         t.box.push_back(Box{}); t.left.push_back(MIRT_CHILD_NONE); t.right.push_back(MIRT_CHILD_NONE);
@@ -85,17 +95,33 @@ struct Builder {
         else if (n == 2) { l = ~(int32_t)o[0]; r = ~(int32_t)o[1]; }
         else {
             float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-            for (size_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) {
-                float c = s.prim_off[3 * (size_t)s.obj_first[o[i]] + a];
-                lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c);
-            }
+            for (size_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) { float c = centroid(o[i], a); lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
             int ax = 0; if (hi[1] - lo[1] > hi[ax] - lo[ax]) ax = 1; if (hi[2] - lo[2] > hi[ax] - lo[ax]) ax = 2;
-            size_t half = n / 2;
-            std::nth_element(o, o + half, o + n, [&](uint32_t x, uint32_t y) {
-                float cx = s.prim_off[3 * (size_t)s.obj_first[x] + ax], cy = s.prim_off[3 * (size_t)s.obj_first[y] + ax];
-                return cx < cy || (cx == cy && x < y);
-            });
-            l = build(o, half); r = build(o + half, n - half);
+            size_t half = 0;
+            const float ext = hi[ax] - lo[ax];
+            if (depth < kSahDepth && ext > 0.0f && std::isfinite(ext)) {
+                Box bb[kBins]; size_t cnt[kBins] = {};
+                for (int b = 0; b < kBins; ++b) for (int a = 0; a < 3; ++a) { bb[b].mn[a] = FLT_MAX; bb[b].mx[a] = -FLT_MAX; }
+                auto bin_of = [&](uint32_t x) { int b = (int)((centroid(x, ax) - lo[ax]) / ext * kBins); return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b); };
+                for (size_t i = 0; i < n; ++i) { int b = bin_of(o[i]); bb[b] = cnt[b] ? combine(bb[b], ob[o[i]]) : ob[o[i]]; cnt[b]++; }
+                float rarea[kBins]; size_t rcnt[kBins]; Box acc{}; size_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { if (cnt[b]) { acc = c ? combine(acc, bb[b]) : bb[b]; c += cnt[b]; } rarea[b] = c ? area(acc) : 0.0f; rcnt[b] = c; }
+                float best = FLT_MAX; int cut = -1; c = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    if (cnt[b]) { acc = c ? combine(acc, bb[b]) : bb[b]; c += cnt[b]; }
+                    if (!c || !rcnt[b + 1]) continue;
+                    float cost = area(acc) * (float)c + rarea[b + 1] * (float)rcnt[b + 1];
+                    if (cost < best) { best = cost; cut = b; }
+                }
+                if (cut >= 0) half = (size_t)(std::partition(o, o + n, [&](uint32_t x) { return bin_of(x) <= cut; }) - o);
+            }
+            if (half == 0 || half == n) {                       // median on the same axis
+                half = n / 2;
+                std::nth_element(o, o + half, o + n, [&](uint32_t x, uint32_t y) { float cx = centroid(x, ax), cy = centroid(y, ax); return cx < cy || (cx == cy && x < y); });
+            }
+            // a side of one object becomes a child directly (a node over a single object would only add a box test)
+            l = half == 1 ? ~(int32_t)o[0] : build(o, half, depth + 1);
+            r = n - half == 1 ? ~(int32_t)o[half] : build(o + half, n - half, depth + 1);
         }
         auto cb = [&](int32_t c) { return c < 0 ? ob[~c] : t.box[c]; };
         t.box[me] = (r == MIRT_CHILD_NONE) ? cb(l) : combine(cb(l), cb(r));
@@ -138,13 +164,14 @@ inline std::string validate(const mirt_scene &s)
 inline std::string prepare_tree(const mirt_scene &s, Tree &out)
 {
     Tree t;
+    out.obox.resize(s.n_objects);
+    for (uint32_t o = 0; o < s.n_objects; ++o) out.obox[o] = object_box(s, o);
     if (s.n_nodes) {
         t.box.resize(s.n_nodes); t.left.assign(s.node_left, s.node_left + s.n_nodes); t.right.assign(s.node_right, s.node_right + s.n_nodes);
         for (uint32_t i = 0; i < s.n_nodes; ++i) for (int a = 0; a < 3; ++a) { t.box[i].mn[a] = s.node_min[3 * (size_t)i + a]; t.box[i].mx[a] = s.node_max[3 * (size_t)i + a]; }
         t.root = s.root;
     } else {
-        std::vector<Box> ob(s.n_objects);
-        for (uint32_t o = 0; o < s.n_objects; ++o) ob[o] = object_box(s, o);
+        const std::vector<Box> &ob = out.obox;
         std::vector<uint32_t> idx(s.n_objects);
         for (uint32_t o = 0; o < s.n_objects; ++o) idx[o] = o;
         Builder b{ s, ob, t };

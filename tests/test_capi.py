@@ -88,3 +88,33 @@ def test_spp_ranges_tile_the_sample_space():
             for (b0, n0), (b1, _) in zip(r, r[1:]):
                 assert b0 + n0 == b1
     assert [sharding.spp_range(k, 8, 1024) for k in (0, 7)] == [(0, 128), (896, 128)]
+
+
+def test_own_bvh_builder_makes_valid_trees():
+    """mirt_build_bvh (host-only): every object is a leaf exactly once, every box contains its children, and the
+    oracle finds the same closest t through it as through the list."""
+    from tests import orc
+    from tests import helpers as H
+    for mk in (lambda: scene.cornell_box(1.0), lambda: scene.cornell_two_boxes(1.0), lambda: scene.spheres_world(1.5)):
+        s, cam = mk()
+        depth = capi.build_bvh(s)
+        mn, mx, l, r, root = s.nodes
+        omn, omx = orc.object_bounds(s)
+        seen = []
+        def walk(c, lvl):
+            if c == capi.CHILD_NONE:
+                return None
+            if c < 0:
+                seen.append(~c); return omn[~c], omx[~c], lvl
+            boxes = [b for b in (walk(l[c], lvl + 1), walk(r[c], lvl + 1)) if b is not None]
+            for bmn, bmx, _ in boxes:
+                assert (mn[c] <= bmn).all() and (mx[c] >= bmx).all()
+            return mn[c], mx[c], max(b[2] for b in boxes)
+        assert walk(root, 1)[2] - 1 == depth
+        assert sorted(seen) == list(range(s.n_objects))
+        org, d = H.ray_batch(4096, 5, extent=6.0)
+        a, sa = orc.world_hit_batch(s, org, d, 0.001, 3.0e38, 0)
+        b, sb = orc.world_hit_batch(s, org, d, 0.001, 3.0e38, orc.FLAG_ACCEL_LIST)
+        H.assert_bits(a["t"], b["t"], "own tree vs list")
+        if s.n_objects > 100:
+            assert sa.prims_tested < 0.05 * sb.prims_tested            # the tree prunes

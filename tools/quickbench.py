@@ -21,5 +21,5 @@ for rep in range(reps):
     print(f"{world} {w}x{h}@{spp}: device {st.device_ms:.2f} ms  {st.samples / st.device_ms / 1e3:.1f} Msamples/s  "
           f"{st.rays / st.device_ms / 1e6:.2f} Grays/s  first {st.first_ms:.2f} ms  deeper {st.extend_ms:.2f} ms  rays/sample {st.rays / st.samples:.3f}", flush=True)
     if os.environ.get("MIRT_PER_DEPTH"):
-        h = list(st.depth_hist); ms = list(st.depth_ms)
-        print("  depth: Mrays, ms, Grays/s: " + "  ".join(f"{d}:{h[d] / 1e6:.1f},{ms[d]:.2f},{h[d] / ms[d] / 1e6:.1f}" for d in range(0, 12) if ms[d] > 0), flush=True)
+        hh = list(st.depth_hist); ms = list(st.depth_ms)
+        print("  depth: Mrays, ms, Grays/s: " + "  ".join(f"{d}:{hh[d] / 1e6:.1f},{ms[d]:.2f},{hh[d] / ms[d] / 1e6:.1f}" for d in range(0, 12) if ms[d] > 0), flush=True)
