@@ -231,12 +231,34 @@ class _HostRng:
         return F(self.buf.pop(0) / 4294967296.0)
 
 
-def spheres_world(aspect=1.5, small_spheres=True, seed=1, grid=11):
+def _philox_np(counters, key):
+    """Philox4x32-10 over an (n,4) uint32 counter array (vectorised twin of _HostRng.philox)."""
+    c = [counters[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]; p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32, p1 & m32, ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32, p0 & m32]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32; k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def _host_draws(seed, first, count):
+    """Raw draws [first, first+count) of the _HostRng(seed) stream, vectorised."""
+    b0, b1 = first // 4, (first + count + 3) // 4
+    ctr = np.zeros((b1 - b0, 4), np.uint32)
+    ctr[:, 0] = np.arange(b0, b1, dtype=np.uint64).astype(np.uint32); ctr[:, 3] = 0x5CE9E
+    raw = _philox_np(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(-1)
+    return raw[first - 4 * b0: first - 4 * b0 + count]
+
+
+def spheres_world(aspect=1.5, small_spheres=True, seed=1, grid=11, look_from=(11.0, 2.0, 3.0)):
     """WORLD_ID_RANDOM_SPHERES, World.cpp:25-67.  small_spheres=False is the `#if 1` block at :36
     disabled (BASELINE config 1, the 4-sphere scene); grid=11 is the reference's a,b in [-11,11),
-    larger grids extend the same generator (BASELINE config 4).  The reference draws positions and
-    the 50+50 random materials from std::random_device; here they come from Philox(seed) in the
-    reference's draw order (Resouces.cpp:110-124 first, then World.cpp:41-54)."""
+    larger grids extend the same generator (BASELINE config 4: grid=500 -> ~1M spheres, look_from raised).
+    The reference draws positions and the 50+50 random materials from std::random_device; here they come
+    from Philox(seed) in the reference's draw order (Resouces.cpp:110-124 first, then World.cpp:41-54:
+    chooseMat, x jitter, z jitter, and a material pick only for kept non-glass spheres)."""
     g = _HostRng(seed)
     s = FlatScene(ambient=(0.85, 0.9, 1.0))                            # World.cpp:63
     rl = [s.lambertian((float(g.unorm() * g.unorm()), float(g.unorm() * g.unorm()), float(g.unorm() * g.unorm()))) for _ in range(50)]
@@ -246,22 +268,38 @@ def spheres_world(aspect=1.5, small_spheres=True, seed=1, grid=11):
         rm.append(s.metal(alb, float(F(0.5) * g.unorm())))
     lam0 = s.lambertian((0.5, 0.5, 0.5)); lam1 = s.lambertian((0.4, 0.2, 0.1))
     metal = s.metal((0.7, 0.6, 0.5), 0.0); glass = s.dielectric(1.5)
+    assert (rl[0], rm[0], lam0, glass) == (0, 50, 100, 103)
     s.sphere((0.0, -1000.0, -0.0), 1000.0, lam0)                       # :28
     s.sphere((-4.0, 1.0, 0.0), 1.0, lam1)                              # :31
     s.sphere((0.0, 1.0, 0.0), 1.0, glass)                              # :32
     s.sphere((4.0, 1.0, 0.0), 1.0, metal)                              # :33
     if small_spheres:
-        for a in range(-grid, grid):
-            for b in range(-grid, grid):
-                choose = g.unorm()
-                cx = F(a) + F(0.9) * g.unorm(); cz = F(b) + F(0.9) * g.unorm()
-                d = np.array([cx - F(4.0), F(0.2) - F(0.2), cz - F(0.0)], F)
-                if np.sqrt(_dot(d, d)) > F(0.9):                       # :43
-                    m = glass
-                    if choose < F(0.8):
-                        m = rl[min(int(g.unorm() * F(50)), 49)]
-                    elif choose < F(0.95):
-                        m = rm[min(int(g.unorm() * F(50)), 49)]
-                    s.sphere((float(cx), 0.2, float(cz)), 0.2, m)      # :57
-    cam = make_camera((11.0, 2.0, 3.0), (0.0, 0.6, 0.0), 20.0, 0.1, aspect)   # :64
+        # The material pick consumes a draw only for kept non-glass spheres, so a cell's draws depend on all
+        # earlier cells.  Cells are processed in blocks: draw a generous window, then resolve offsets by a scan.
+        ncell = (2 * grid) ** 2
+        raw = _host_draws(seed, 500, 4 * ncell)                         # 500 = the palette draws above
+        un = (raw.astype(np.float64) / 4294967296.0).astype(F)
+        aa = np.repeat(np.arange(-grid, grid), 2 * grid).astype(F); bb = np.tile(np.arange(-grid, grid), 2 * grid).astype(F)
+        cen = np.zeros((ncell, 3), F); mats = np.zeros(ncell, np.int64); keep = np.zeros(ncell, bool)
+        pos = 0
+        for i in range(ncell):                                          # scalar scan over cells, vector draws
+            choose, ux, uz = un[pos], un[pos + 1], un[pos + 2]; pos += 3
+            cx = aa[i] + F(0.9) * ux; cz = bb[i] + F(0.9) * uz
+            dx = cx - F(4.0); dz = cz - F(0.0)
+            if np.sqrt(F(F(dx * dx) + F(0.0)) + F(dz * dz)) > F(0.9):   # :43
+                m = glass
+                if choose < F(0.8):
+                    m = int(F(0.0) + un[pos] * F(50)); pos += 1        # :49 (START + u*COUNT, truncated)
+                elif choose < F(0.95):
+                    m = int(F(50.0) + un[pos] * F(50)); pos += 1       # :54
+                keep[i] = True; mats[i] = m; cen[i] = (cx, F(0.2), cz)
+        k = int(keep.sum())
+        base = len(s.kind)
+        s.kind += [capi.PRIM_SPHERE] * k
+        s.off += [tuple(float(v) for v in c) for c in cen[keep]]
+        s.geom += [(0.2, 0, 0, 0, 0)] * k
+        s.axes += [0] * k; s.rot += [(0, 1, 0, 1, 0, 1)] * k; s.pmat += [int(m) for m in mats[keep]]
+        s.obj_first += list(range(base, base + k)); s.obj_count += [1] * k
+        s._arrays = None
+    cam = make_camera(look_from, (0.0, 0.6, 0.0), 20.0, 0.1, aspect)   # :64
     return s, cam

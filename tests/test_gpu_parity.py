@@ -222,3 +222,27 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     g1 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0)
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
     H.assert_hits_equal(g1, o1, "own tree, reference order", uv_tol=2e-6)
+
+
+def test_million_spheres(gpu, orc):
+    """BASELINE config 4 (the generator of World.cpp:36-58 extended to a 1000x1000 grid, ~1M spheres): the host-built
+    SAH tree is walked in the reference's order by the oracle and by the device (bit-exact hits and image), and
+    near-first by the device (same closest t, same image: no coplanar surfaces here)."""
+    s, cam = scene.spheres_world(1.5, grid=500, look_from=(26.0, 6.0, 6.0))
+    assert s.n_objects > 900000
+    depth = capi.build_bvh(s)
+    assert 20 <= depth <= 60
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    org, d = H.ray_batch(8192, 31, extent=40.0)
+    d[:, 1] = -np.abs(d[:, 1])                                  # look down at the field
+    o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
+    assert (o["prim"] > 3).sum() > 200                           # small spheres are being hit, not just the ground
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o, "1M ref order", uv_tol=2e-6)
+    g2 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
+    H.assert_bits(g2["t"], o["t"], "1M near-first t"); assert np.array_equal(g2["prim"], o["prim"])
+    w, h = 96, 64
+    osum, ost = orc.trace(s, cam, w, h, 2, 50, 11, 0)
+    for flags in (0, capi.FLAG_ACCEL_ORDERED):
+        g = gpu.render(w, h, 2, 50, 11, flags)
+        H.assert_bits(g["sum"], osum, f"1M image flags={flags}")
+        assert g["stats"].rays == ost.rays

@@ -7,7 +7,12 @@ from raytracinginaweekend_amd import capi, scene
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 world = sys.argv[2] if len(sys.argv) > 2 else "cornell"
 w, h = (1024, 1024) if world == "cornell" else (1200, 800)
-s, cam = scene.cornell_box(1.0) if world == "cornell" else scene.spheres_world(w / h)
+if world == "cornell":
+    s, cam = scene.cornell_box(1.0)
+elif world == "spheres1m":                    # BASELINE config 4: ~1M spheres, camera raised to see the field
+    s, cam = scene.spheres_world(w / h, grid=500, look_from=(26.0, 6.0, 6.0))
+else:
+    s, cam = scene.spheres_world(w / h)
 ctx = capi.Context(0)
 ctx.upload_scene(s); ctx.set_camera(cam)
 ctx.set_option("time_launches", 1)
