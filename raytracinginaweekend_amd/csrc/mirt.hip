@@ -41,10 +41,13 @@ struct mirt_ctx {
     bool prims_in_lds = false;
     mirt_camera cam{};
     DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats;
+    DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
     uint32_t blocks_per_cu = 8;
+    uint32_t lds_budget = 20u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
+    uint32_t stack_lds = 12;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
@@ -91,7 +94,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_spill, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -110,7 +113,9 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
         return MIRT_OK;
     }
     if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
-    if (!strcmp(name, "blocks_per_cu")) { if (value < 1 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "lds_budget")) { if (value < 4096 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_budget out of range"); c->lds_budget = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
 }
 
@@ -189,10 +194,14 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
     d.root = tree.root;
     for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];
-    // LDS plan, <= 40 KiB per workgroup so four workgroups share a CU's 160 KiB
-    const uint32_t budget = 40u * 1024u;
+    // LDS plan: the short part of the traversal stack, the material table, small primitive tables, and whatever
+    // is left of the budget for the top of the tree.  Occupancy beats LDS-resident nodes (measured: 1M spheres,
+    // 40 KiB plan 2.07 Grays/s, 8 KiB plan 2.65), so the default budget is small.
+    const uint32_t budget = c->lds_budget;
     d.stack_depth = tree.depth + 1;
-    uint32_t used = d.stack_depth * MIRT_BLOCK * 4u;
+    d.stack_lds = std::min<uint32_t>(d.stack_depth, c->stack_lds);
+    d.spill = nullptr; d.spill_stride = 0;
+    uint32_t used = d.stack_lds * MIRT_BLOCK * 4u;
     d.lds_mats = (s->n_mats * sizeof(MatRec) <= 6u * 1024u) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
     c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 16u * 1024u;
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
@@ -245,6 +254,16 @@ static int accel_mode(const mirt_ctx *c, uint32_t flags)
     return 1;
 }
 
+// Points sd's spill area at a buffer large enough for `grid` workgroups.
+static int bind_spill(mirt_ctx *c, SceneDev &sd, uint32_t grid)
+{
+    const uint32_t levels = sd.stack_depth - sd.stack_lds;
+    sd.spill_stride = grid * MIRT_BLOCK;
+    if (levels && c->d_spill.ensure((size_t)levels * sd.spill_stride * sizeof(int32_t))) return -1;
+    sd.spill = (int32_t *)c->d_spill.p;
+    return 0;
+}
+
 template <bool FIRST>
 static void launch_bounce(const mirt_ctx *c, int mode, const BounceArgs &a, uint32_t grid, hipStream_t st)
 {
@@ -254,6 +273,20 @@ static void launch_bounce(const mirt_ctx *c, int mode, const BounceArgs &a, uint
     if (mode == 0) { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 0, false>), g, b, lds, st, a); }
     else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 1, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 1, false>), g, b, lds, st, a); }
     else { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 2, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 2, false>), g, b, lds, st, a); }
+}
+
+// Workgroups of the depth>=1 kernel that fit on one CU with this scene's LDS plan (the persistent grid is sized to it).
+static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
+{
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const bool pl = c->prims_in_lds;
+    int n = 0;
+    hipError_t e;
+    if (mode == 0) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 0, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 0, false>, MIRT_BLOCK, lds);
+    else if (mode == 1) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 1, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 1, false>, MIRT_BLOCK, lds);
+    else e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 2, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_bounce<false, 2, false>, MIRT_BLOCK, lds);
+    if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 8; }
+    return (uint32_t)n;
 }
 
 static PathQ carve_queue(float4 *base, size_t cap)
@@ -289,8 +322,10 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const uint32_t n_pix_tiles = (uint32_t)((npix_total + npix_b - 1) / npix_b);
     const uint32_t n_s_tiles = (spp_count + S - 1) / S;
     const uint32_t n_batches = n_pix_tiles * n_s_tiles;
-    const uint32_t n_depth = p->max_depth + 2;            // per depth d: [0] slots reserved in, [1] paths entering bounce d
-    const uint32_t max_grid = (uint32_t)c->n_cu * c->blocks_per_cu;
+    const uint32_t n_depth = p->max_depth + 2;            // per depth d: [0] slots reserved in, [1] paths entering bounce d, [2] work cursor
+    const uint32_t per_cu = c->blocks_per_cu ? c->blocks_per_cu : bounce_occupancy(c, mode);
+    if (getenv("MIRT_DEBUG")) fprintf(stderr, "[mirt] mode %d, lds %u B, %u workgroups/CU (occupancy query %u)\n", mode, mode == 2 ? c->lds_bytes2 : c->lds_bytes, per_cu, bounce_occupancy(c, mode));
+    const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
     // out-queue chunk size (slots a workgroup reserves with one atomic) and the slot capacity that makes an
     // overflow impossible: a closed chunk holds > chunk-256 paths, every workgroup leaves one open chunk
     const uint32_t grid_max = (uint32_t)std::min<uint64_t>((capq + MIRT_BLOCK - 1) / MIRT_BLOCK, max_grid);
@@ -298,21 +333,22 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const uint64_t chunk = 1ull << chunk_shift;
     const uint64_t n_chunks_max = capq / (chunk - 255) + grid_max + 2;
     const uint64_t cap_slots = n_chunks_max * chunk;
-    if (cap_slots > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: ray queue larger than 2^32 slots (lower max_paths)");
+    if (cap_slots > 0xFFFF0000ull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: ray queue larger than 2^32 slots (lower max_paths)");
 
     if (c->d_queues.ensure(2 * 3 * cap_slots * sizeof(float4)) || c->d_rad.ensure(capq * sizeof(float4)) ||
-        c->d_counts.ensure(((size_t)n_batches * n_depth * 2 + 1) * sizeof(uint32_t)) || c->d_len.ensure(2 * n_chunks_max * sizeof(uint32_t)))
+        c->d_counts.ensure(((size_t)n_batches * n_depth * 3 + 1) * sizeof(uint32_t)) || c->d_len.ensure(2 * n_chunks_max * sizeof(uint32_t)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the ray queues failed (lower the max_paths option)");
     PathQ q[2] = { carve_queue((float4 *)c->d_queues.p, cap_slots), carve_queue((float4 *)c->d_queues.p + 3 * cap_slots, cap_slots) };
     uint32_t *qlen[2] = { (uint32_t *)c->d_len.p, (uint32_t *)c->d_len.p + n_chunks_max };
     uint32_t *counts = (uint32_t *)c->d_counts.p;
-    const size_t n_counts = (size_t)n_batches * n_depth * 2 + 1;
+    const size_t n_counts = (size_t)n_batches * n_depth * 3 + 1;
     uint32_t *overflow = counts + n_counts - 1;
     HIPCHK(c, hipMemsetAsync(counts, 0, n_counts * sizeof(uint32_t), st));
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
 
     BounceArgs a{};
-    a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam;
+    if (bind_spill(c, a.sc, grid_max)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed"); a.rad = (float4 *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
 #ifdef MIRT_STAMPS
@@ -336,13 +372,13 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
             const uint32_t s0 = spp_begin + stile * S;
             const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
             const uint32_t n_first = np * ns;
-            uint32_t *cnt = counts + (size_t)batch * n_depth * 2;
+            uint32_t *cnt = counts + (size_t)batch * n_depth * 3;
             a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_first = n_first;
             const uint32_t grid = std::min<uint32_t>((n_first + MIRT_BLOCK - 1) / MIRT_BLOCK, max_grid);
             for (uint32_t d = 0; d <= p->max_depth; ++d) {
                 a.depth = d;
                 a.in = q[d & 1]; a.out = q[(d + 1) & 1];
-                a.res_in = cnt + 2 * d; a.res_out = cnt + 2 * (d + 1); a.alive_out = cnt + 2 * (d + 1) + 1;
+                a.res_in = cnt + 3 * d; a.cursor = cnt + 3 * d + 2; a.res_out = cnt + 3 * (d + 1); a.alive_out = cnt + 3 * (d + 1) + 1;
                 a.len_in = qlen[d & 1]; a.len_out = qlen[(d + 1) & 1];
                 if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * ev_first.size()], st));
                 if (d == 0) launch_bounce<true>(c, mode, a, grid, st);
@@ -384,7 +420,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
         stats->depth_hist[0] = stats->samples;
         for (uint32_t b = 0; b < n_batches; ++b)
             for (uint32_t d = 1; d <= p->max_depth; ++d) {
-                uint64_t v = h[((size_t)b * n_depth + d) * 2 + 1];
+                uint64_t v = h[((size_t)b * n_depth + d) * 3 + 1];
                 stats->rays += v; stats->depth_hist[d < 63 ? d : 63] += v;
             }
     }
@@ -483,11 +519,12 @@ extern "C" int mirt_world_hit_batch(mirt_ctx *c, const float *org, const float *
     float *dorg = t.up(org, 3 * nray), *ddir = t.up(dir, 3 * nray);
     mirt_hit *dout = t.up<mirt_hit>(nullptr, nray);
     NEED(dorg && ddir && dout);
-    dim3 g((uint32_t)((nray + MIRT_BLOCK - 1) / MIRT_BLOCK)), b(MIRT_BLOCK);
+    dim3 g((uint32_t)std::min<size_t>((nray + MIRT_BLOCK - 1) / MIRT_BLOCK, (size_t)c->n_cu * 16)), b(MIRT_BLOCK);
     const int mode = accel_mode(c, flags);
     const bool pl = c->prims_in_lds;
     const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
-    const SceneDev &sd = mode == 2 ? c->sc2 : c->sc;
+    SceneDev sd = mode == 2 ? c->sc2 : c->sc;
+    if (bind_spill(c, sd, g.x)) return fail(c, MIRT_ERR_NOMEM, "mirt_world_hit_batch: hipMalloc of the traversal-stack spill area failed");
     if (mode == 0) { if (pl) hipLaunchKernelGGL((k_world_hit_batch<0, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<0, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
     else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_world_hit_batch<1, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<1, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
     else { if (pl) hipLaunchKernelGGL((k_world_hit_batch<2, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<2, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }

@@ -43,6 +43,11 @@ struct SceneDev {
     float   ambient[3];
     // dynamic-LDS plan (in records): [prims][nodes][mats][stack]
     uint32_t lds_prims, lds_nodes, lds_mats, stack_depth;
+    // traversal stack: levels [0, stack_lds) live in LDS ([level][lane]); deeper levels -- rare with a good tree
+    // walked near-first -- go to `spill` in HBM, [level - stack_lds][thread of the grid].  Keeping the LDS part
+    // short is what lets 8 workgroups share a CU.
+    uint32_t stack_lds, spill_stride;
+    int32_t *spill;
 };
 
 struct BounceArgs {
@@ -54,6 +59,9 @@ struct BounceArgs {
     // len[c] = slots of chunk c that hold paths; the unused tail of a chunk is skipped by the reader.
     const uint32_t *res_in;        // slots reserved in the in-queue (multiple of the chunk size)
     const uint32_t *len_in;
+    uint32_t *cursor;              // next unclaimed work unit of the in-queue: workgroups claim units (a chunk, or a
+                                   // power-of-two part of one when the queue is short) dynamically, so a launch
+                                   // balances itself whatever the grid size and residency turn out to be
     uint32_t *res_out;
     uint32_t *len_out;
     uint32_t *alive_out;           // paths written to the out-queue (statistics: rays of the next depth)
@@ -90,6 +98,23 @@ struct BounceArgs {
 // ---------------------------------------------------------------------------------- LDS staging
 struct LdsView {
     PrimRec *prims; unsigned char *nodes; MatRec *mats; int32_t *stack;
+};
+struct Stack {                       // one lane's traversal stack (see SceneDev::stack_lds)
+    int32_t *lds, *hbm; uint32_t n_lds, n_all, stride, sp;
+    __device__ __forceinline__ Stack(const SceneDev &sc, const LdsView &v)
+        : lds(v.stack + threadIdx.x), hbm(sc.spill + (blockIdx.x * MIRT_BLOCK + threadIdx.x)), n_lds(sc.stack_lds), n_all(sc.stack_depth),
+          stride(sc.spill_stride), sp(0) {}
+    __device__ __forceinline__ void push(int32_t x)
+    {
+        if (sp >= n_all) return;                              // cannot happen: n_all = tree depth + 1
+        if (sp < n_lds) lds[sp * MIRT_BLOCK] = x; else hbm[(size_t)(sp - n_lds) * stride] = x;
+        ++sp;
+    }
+    __device__ __forceinline__ int32_t pop()
+    {
+        --sp;
+        return sp < n_lds ? lds[sp * MIRT_BLOCK] : hbm[(size_t)(sp - n_lds) * stride];
+    }
 };
 __device__ __forceinline__ LdsView lds_view(const SceneDev &sc, unsigned char *base)
 {
@@ -141,8 +166,7 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
                                                float t_min, float &t_max)
 {
     int32_t best = -1;
-    int32_t *stk = v.stack + threadIdx.x;
-    uint32_t sp = 0;
+    Stack stk(sc, v);
     int32_t cur = sc.root;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
     for (;;) {
@@ -156,7 +180,7 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
                 n.mx[0] = b.x; n.mx[1] = b.y; n.mx[2] = b.z; n.right = __float_as_int(b.w);
             }
             if (aabb_hit(n.mn, n.mx, o, d, t_min, t_max)) {
-                if (n.right != MIRT_CHILD_NONE && sp < sc.stack_depth) { stk[sp * MIRT_BLOCK] = n.right; ++sp; }
+                if (n.right != MIRT_CHILD_NONE) stk.push(n.right);
                 cur = n.left;
                 continue;
             }
@@ -168,8 +192,8 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
                 if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
             }
         }
-        if (sp == 0) break;
-        --sp; cur = stk[sp * MIRT_BLOCK];
+        if (stk.sp == 0) break;
+        cur = stk.pop();
     }
     return best;
 }
@@ -199,8 +223,7 @@ template <bool PLDS>
 __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max)
 {
     int32_t best = -1;
-    int32_t *stk = v.stack + threadIdx.x;
-    uint32_t sp = 0;
+    Stack stk(sc, v);
     int32_t cur = sc.root;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
     const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
@@ -221,7 +244,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 const int32_t far = left_first ? n.right : n.left;
-                if (sp < sc.stack_depth) { stk[sp * MIRT_BLOCK] = far; ++sp; }
+                stk.push(far);
                 cur = left_first ? n.left : n.right;
                 continue;
             }
@@ -235,8 +258,8 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                 if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
             }
         }
-        if (sp == 0) break;
-        --sp; cur = stk[sp * MIRT_BLOCK];
+        if (stk.sp == 0) break;
+        cur = stk.pop();
     }
     return best;
 }
@@ -345,8 +368,11 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
     __shared__ uint32_t s_base[2];
     __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
 
+    __shared__ uint32_t s_work;
     const uint32_t n_in = FIRST ? a.n_first : *a.res_in;
-    if (blockIdx.x * MIRT_BLOCK >= n_in) return;
+    uint32_t ush = a.chunk_shift;                                  // unit = 1 << ush slots, >= 4 units per workgroup if possible
+    while (ush > 8u && (n_in >> ush) < gridDim.x * 4u) --ush;
+    if (((uint64_t)blockIdx.x << ush) >= n_in) return;
     const LdsView lv = lds_view(a.sc, smem);
     lds_stage(a.sc, lv);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -355,17 +381,22 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
     uint32_t ck_base = 0xFFFFFFFFu, ck_next = 0, blk_alive = 0, par = 0;
     STAMP_DECL;
 
-    for (uint32_t base = blockIdx.x * MIRT_BLOCK; base < n_in; base += gridDim.x * MIRT_BLOCK) {
+    for (;;) {
+      if (threadIdx.x == 0) s_work = atomicAdd(a.cursor, 1u);
+      __syncthreads();
+      const uint32_t ci = s_work;
+      __syncthreads();                                                          // s_work is rewritten next round
+      const uint64_t ubase = (uint64_t)ci << ush;
+      if (ubase >= n_in) break;
+      // the unit's paths end where its chunk's filled part ends (the tail of a chunk is unused)
+      const uint64_t cbase = ubase & ~(uint64_t)(chunk - 1u);
+      const uint64_t filled = FIRST ? (uint64_t)n_in : cbase + a.len_in[ubase >> a.chunk_shift];   // uniform
+      const uint64_t uend = ubase + (1ull << ush);
+      const uint32_t stop = (uint32_t)(filled < uend ? filled : uend);
+      for (uint32_t base = (uint32_t)ubase; base < stop; base += MIRT_BLOCK) {
         STAMP(7);
         const uint32_t idx = base + threadIdx.x;
-        bool active;
-        if (FIRST) active = idx < n_in;
-        else {
-            const uint32_t len = a.len_in[base >> a.chunk_shift];           // wave-uniform
-            const uint32_t in_chunk = base & (chunk - 1u);
-            if (in_chunk >= len) continue;                                      // unused tail of a chunk (uniform)
-            active = in_chunk + threadIdx.x < len;
-        }
+        const bool active = idx < stop;
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
         uint32_t pixel = 0, sample = 0;
         if (active) {
@@ -466,8 +497,9 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             a.out.p1[pos] = make_float4(nd.y, nd.z, thr.x, thr.y);
             a.out.p2[pos] = make_float4(thr.z, __uint_as_float(pixel), __uint_as_float(sample), 0.0f);
         }
-        par ^= 1u;                             // flips only on executed iterations (the skip above has no barriers)
+        par ^= 1u;
         STAMP(6);
+      }
     }
     if (threadIdx.x == 0) {
         if (ck_base != 0xFFFFFFFFu) a.len_out[ck_base >> a.chunk_shift] = ck_next - ck_base;
@@ -555,16 +587,16 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_world_hit_batch(SceneDev sc, con
     extern __shared__ __align__(16) unsigned char smem[];
     const LdsView lv = lds_view(sc, smem);
     lds_stage(sc, lv);
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nray) return;
-    f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
-    float tm = t_max;
-    int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm)
-                 : (ACCEL == 1 ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm));
-    Hit h;
-    const PrimRec *P = PLDS ? lv.prims : sc.prims;
-    if (best >= 0) prim_record(P[best], best, o, d, tm, true, h);
-    store_hit(out + i, h, best >= 0);
+    for (uint32_t i = blockIdx.x * MIRT_BLOCK + threadIdx.x; i < nray; i += gridDim.x * MIRT_BLOCK) {
+        f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
+        float tm = t_max;
+        int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm)
+                     : (ACCEL == 1 ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm));
+        Hit h;
+        const PrimRec *P = PLDS ? lv.prims : sc.prims;
+        if (best >= 0) prim_record(P[best], best, o, d, tm, true, h);
+        store_hit(out + i, h, best >= 0);
+    }
 }
 
 __global__ void k_scatter_batch(SceneDev sc, const mirt_hit *hits, const float *dir_in, uint32_t n, const uint32_t *draws,

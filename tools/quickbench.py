@@ -14,11 +14,11 @@ elif world == "spheres1m":                    # BASELINE config 4: ~1M spheres, 
 else:
     s, cam = scene.spheres_world(w / h)
 ctx = capi.Context(0)
-ctx.upload_scene(s); ctx.set_camera(cam)
 ctx.set_option("time_launches", 1)
 for kv in os.environ.get("MIRT_OPTS", "").split(","):
     if "=" in kv:
         ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+ctx.upload_scene(s); ctx.set_camera(cam)
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 for rep in range(reps):
     r = ctx.render(w, h, spp, int(os.environ.get('MIRT_DEPTH', '50')), 0x5EED, capi.FLAG_ACCEL_AUTO, want=())
