@@ -45,8 +45,9 @@ struct mirt_ctx {
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
-    uint32_t blocks_per_cu = 8;
+    uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
     uint32_t lds_budget = 20u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
+    uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t stack_lds = 12;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -114,6 +115,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     }
     if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
     if (!strcmp(name, "lds_budget")) { if (value < 4096 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_budget out of range"); c->lds_budget = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "engine")) { if (value < 0 || value > 1) return fail(c, MIRT_ERR_ARG, "engine must be 0 (wavefront) or 1 (persistent)"); c->engine = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
@@ -289,6 +291,93 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
     return (uint32_t)n;
 }
 
+static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
+{
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const bool pl = c->prims_in_lds;
+    dim3 g(grid), b(MIRT_BLOCK);
+    if (mode == 0) { if (pl) hipLaunchKernelGGL((k_trace<0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<0, false>), g, b, lds, st, a); }
+    else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_trace<1, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<1, false>), g, b, lds, st, a); }
+    else { if (pl) hipLaunchKernelGGL((k_trace<2, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<2, false>), g, b, lds, st, a); }
+}
+static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
+{
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const bool pl = c->prims_in_lds;
+    int n = 0;
+    hipError_t e;
+    if (mode == 0) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<0, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<0, false>, MIRT_BLOCK, lds);
+    else if (mode == 1) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<1, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<1, false>, MIRT_BLOCK, lds);
+    else e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<2, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<2, false>, MIRT_BLOCK, lds);
+    if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 8; }
+    return (uint32_t)n;
+}
+
+// The persistent engine: one k_trace launch + one k_accumulate per batch; no queues.
+static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_sum, hipStream_t st, mirt_stats *stats,
+                             int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp)
+{
+    const uint64_t npix_total = (uint64_t)p->width * p->height;
+    const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
+    const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
+    const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
+    const size_t capq = (size_t)npix_b * S;
+    const uint32_t n_pix_tiles = (uint32_t)((npix_total + npix_b - 1) / npix_b);
+    const uint32_t n_s_tiles = (spp_count + S - 1) / S;
+    const uint32_t n_batches = n_pix_tiles * n_s_tiles;
+    const uint32_t per_cu = c->blocks_per_cu ? c->blocks_per_cu : trace_occupancy(c, mode);
+    if (getenv("MIRT_DEBUG")) fprintf(stderr, "[mirt] persistent engine, mode %d, lds %u B, %u workgroups/CU (occupancy query %u)\n", mode, mode == 2 ? c->lds_bytes2 : c->lds_bytes, per_cu, trace_occupancy(c, mode));
+    const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
+    const size_t per_batch = 66;                           // cursor, hist[65]
+    if (c->d_rad.ensure(capq * sizeof(float4)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
+        return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the radiance slots failed (lower the max_paths option)");
+    uint32_t *counts = (uint32_t *)c->d_counts.p;
+    HIPCHK(c, hipMemsetAsync(counts, 0, n_batches * per_batch * sizeof(uint32_t), st));
+    if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
+
+    TraceArgs a{};
+    a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
+    a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
+    a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+    uint32_t batch = 0;
+    for (uint32_t pt = 0; pt < n_pix_tiles; ++pt) {
+        const uint32_t pix0 = pt * npix_b;
+        const uint32_t np = (uint32_t)std::min<uint64_t>(npix_b, npix_total - pix0);
+        for (uint32_t stile = 0; stile < n_s_tiles; ++stile, ++batch) {
+            const uint32_t s0 = spp_begin + stile * S;
+            const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
+            a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_paths = np * ns;
+            a.cursor = counts + batch * per_batch; a.hist = a.cursor + 1;
+            // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim
+            const uint64_t waves = (uint64_t)max_grid * (MIRT_BLOCK / 64);
+            a.claim = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, max_grid);
+            launch_trace(c, mode, a, grid, st);
+            hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
+                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u);
+        }
+    }
+    HIPCHK(c, hipGetLastError());
+    if (stats) {
+        HIPCHK(c, hipEventRecord(c->ev1, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        std::vector<uint32_t> h(n_batches * per_batch);
+        HIPCHK(c, hipMemcpy(h.data(), counts, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        stats->device_ms = ms; stats->bounce_launches = n_batches; stats->batches = n_batches;
+        stats->samples = npix_total * spp_count;
+        for (uint32_t b = 0; b < n_batches; ++b) {
+            const uint32_t *hist = h.data() + b * per_batch + 1;
+            uint64_t ended_at_or_after = 0;                      // paths that traced a ray at depth d = those ending at depth >= d
+            for (int d = 63; d >= 0; --d) { ended_at_or_after += hist[d]; stats->depth_hist[d] += ended_at_or_after; }
+            stats->depth_hist[63] += hist[64];
+        }
+        for (int d = 0; d < 64; ++d) stats->rays += stats->depth_hist[d];
+    }
+    return MIRT_OK;
+}
+
 static PathQ carve_queue(float4 *base, size_t cap)
 {
     PathQ q;
@@ -313,6 +402,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     const int mode = accel_mode(c, p->flags);
+    if (c->engine == 1) return render_persistent(c, p, d_sum, st, stats, mode, spp_begin, spp_count, one_spp);
 
     // batch geometry: npix_b pixels x S samples <= capacity
     const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);

@@ -266,7 +266,8 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
 
 // ---------------------------------------------------------------------------------- ray generation
 // HomemadeRayTracer.cpp:114-131 + SimpleCamera.cpp:55-60 + Randomizer.h:50-58
-__device__ __forceinline__ void generate_ray(const BounceArgs &a, uint32_t pixel, uint32_t sample, f3 &o, f3 &d)
+template <class Args>
+__device__ __forceinline__ void generate_ray(const Args &a, uint32_t pixel, uint32_t sample, f3 &o, f3 &d)
 {
     uint32_t i = pixel % a.width, j = pixel / a.width;
     PhiloxKeyed g; g.pixel = pixel; g.sample = sample; g.stage = 0; g.k0 = a.k0; g.k1 = a.k1;
@@ -301,7 +302,7 @@ __device__ __forceinline__ void generate_ray(const BounceArgs &a, uint32_t pixel
 // round 0 the still-pending lanes publish their keys in LDS and ALL 64 lanes evaluate candidates for
 // them: with n pending, each gets G = pow2 <= 64/n consecutive iterations in one round.  The owner
 // takes the first accepted iteration, exactly the one its own loop would have stopped at.
-struct CoopLds { uint32_t pix[64], smp[64], it[64]; };
+struct CoopLds { uint32_t pix[64], smp[64], it[64], stg[64]; };
 
 __device__ __forceinline__ f3 sphere_candidate(uint32_t pixel, uint32_t sample, uint32_t stage, uint32_t it, uint32_t k0, uint32_t k1)
 {
@@ -310,7 +311,9 @@ __device__ __forceinline__ f3 sphere_candidate(uint32_t pixel, uint32_t sample, 
     return mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
 }
 
-// need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this)
+// need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this).
+// LSTAGE: the stage (1 + depth) differs from lane to lane (k_trace) and travels with the key.
+template <bool LSTAGE>
 __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t need, uint32_t pixel, uint32_t sample,
                                            uint32_t stage, uint32_t k0, uint32_t k1, f3 &sphere_pt, float &unorm)
 {
@@ -331,7 +334,7 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per pending lane
         const uint32_t G = 1u << lg;
         const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-        if (pending) { cl.pix[rank] = pixel; cl.smp[rank] = sample; cl.it[rank] = next_it; }
+        if (pending) { cl.pix[rank] = pixel; cl.smp[rank] = sample; cl.it[rank] = next_it; if (LSTAGE) cl.stg[rank] = stage; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -341,7 +344,7 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         if (e < n) {
             uint32_t it = cl.it[e] + sub;
             if (it < MIRT_REJECT_CAP) {
-                c = sphere_candidate(cl.pix[e], cl.smp[e], stage, it, k0, k1);
+                c = sphere_candidate(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1);
                 acc = !(dot(c, c) >= 1.0f) || it == MIRT_REJECT_CAP - 1u;        // the cap keeps its last candidate, like the per-lane loop
             }
         }
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         // -------- phase 2 (whole wave): the draws of Scatter
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
         if (EXP_ON(2)) { sp = mk(0.1f, 0.2f, 0.3f); un = 0.5f; }
-        else coop_draws(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
+        else coop_draws<false>(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
         STAMP(2);
         // -------- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         bool alive = false;
@@ -506,6 +509,150 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         if (blk_alive) atomicAdd(a.alive_out, blk_alive);
     }
     STAMP_FLUSH;
+}
+
+
+// ---------------------------------------------------------------------------------- the persistent kernel
+// k_trace: the same per-vertex work as k_bounce (extend, classify, cooperative draws, finish) without the
+// path queues.  Each lane owns one path and walks it bounce after bounce; when the path ends, the lane
+// takes a fresh camera ray.  Camera rays are produced 64 at a time by the whole wave (full lanes, coherent
+// pixels) into a small per-wave LDS stash, so refilling a lane costs a few LDS reads; path ids come from a
+// global cursor in claims of a few hundred, one atomic per claim.  Nothing but the scene and the 16-byte
+// radiance slot per path touches HBM, and one launch serves a whole batch.
+// Every path's arithmetic and Philox keys are those of k_bounce, so the two engines give identical images.
+struct TraceArgs {
+    float4 *rad;
+    uint32_t *cursor;              // next unclaimed path id of the batch
+    uint32_t *hist;                // [0..63] paths ended at depth d (63: at 63 or deeper), [64] vertices beyond depth 63
+    uint32_t n_paths, claim;       // claim: path ids taken per atomic (multiple of 64)
+    SceneDev sc;
+    mirt_camera cam;
+    uint32_t width, height, pix0, npix, spp0;
+    uint32_t max_depth, flags, k0, k1;
+};
+#define MIRT_STASH 128
+struct StashLds { float ox[MIRT_STASH], oy[MIRT_STASH], oz[MIRT_STASH], dx[MIRT_STASH], dy[MIRT_STASH], dz[MIRT_STASH]; uint32_t id[MIRT_STASH]; };
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int ACCEL, bool PLDS>
+__global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
+    __shared__ StashLds s_stash[MIRT_BLOCK / 64];
+    __shared__ uint32_t s_hist[65];
+
+    if ((uint64_t)blockIdx.x * a.claim >= a.n_paths) return;        // more workgroups than claims (uniform)
+    const LdsView lv = lds_view(a.sc, smem);
+    if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
+    lds_stage(a.sc, lv);                                            // ends with a barrier
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    StashLds &stash = s_stash[wave];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // wave-uniform bookkeeping
+    uint32_t cnt = 0;                       // rays in the stash
+    uint32_t w_next = 0, w_end = 0;         // claimed, not yet generated path ids
+    bool exhausted = false;
+    // the lane's path
+    bool live = false;
+    f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
+    uint32_t pid = 0, depth = 0;
+
+    for (;;) {
+        // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
+        if (cnt < 64u && !exhausted) {
+            if (w_next == w_end) {
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(a.cursor, a.claim);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if (b >= a.n_paths) exhausted = true;
+                else { w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim; }
+            }
+            if (!exhausted) {
+                const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
+                if (lane < g) {
+                    const uint32_t id = w_next + lane;
+                    const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
+                    f3 go, gd;
+                    generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
+                    const uint32_t e = cnt + lane;
+                    stash.ox[e] = go.x; stash.oy[e] = go.y; stash.oz[e] = go.z;
+                    stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id;
+                }
+                w_next += g; cnt += g;
+                wave_lds_sync();
+            }
+        }
+        // ---- idle lanes take a fresh path from the top of the stash
+        const unsigned long long idle = __ballot(!live);
+        if (idle != 0ull && cnt != 0u) {
+            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+            if (!live && rank < cnt) {
+                const uint32_t e = cnt - 1u - rank;
+                o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
+                thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
+            }
+            const uint32_t n_idle = (uint32_t)__popcll(idle);
+            cnt -= (n_idle < cnt) ? n_idle : cnt;
+            wave_lds_sync();                                        // the freed entries are rewritten by the next top-up
+        }
+        if (__ballot(live) == 0ull) break;                          // pool exhausted, stash empty, every path ended
+
+        const uint32_t sl = pid / a.npix, pl = pid - sl * a.npix;
+        const uint32_t pixel = a.pix0 + pl, sample = a.spp0 + sl;
+        // ---- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
+        bool done = false;
+        f3 radiance = mk(0.0f, 0.0f, 0.0f);
+        uint32_t need = NEED_NONE;
+        Hit h; h.pos = o; h.nrm = d; h.mat = 0;
+        const MatRec *M = a.sc.mats;
+        if (live) {
+            float t_max = 3.402823466e+38f;   // FLT_MAX
+            const float t_min = 0.001f;
+            const int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
+                               : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
+            if (best < 0) {                                                        // :186
+                radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
+            } else {
+                const PrimRec *P = PLDS ? lv.prims : a.sc.prims;
+                prim_record(P[best], best, o, d, t_max, false, h);
+                if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
+                    radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done = true;
+                } else if (!(depth < a.max_depth)) {                               // :173-174
+                    done = true;
+                } else {
+                    M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
+                    need = scatter_need(M->kind, d, h.nrm, true);
+                }
+            }
+        }
+        // ---- phase 2 (whole wave): the draws of Scatter, keyed by each lane's own depth
+        f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
+        coop_draws<true>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
+        // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
+        if (live && !done) {
+            Scat s;
+            scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
+            if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
+            else { radiance = thr * s.emitted; done = true; }
+        }
+        if (live && done) {
+            a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            atomicAdd(&s_hist[depth < 63u ? depth : 63u], 1u);
+            if (depth > 63u) atomicAdd(&s_hist[64], depth - 63u);
+            live = false;
+        }
+        ++depth;
+    }
+    __syncthreads();
+    if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------- accumulate
