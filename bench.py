@@ -29,8 +29,8 @@ FLOP_PER_SAMPLE_FIXED = 38.0    # ray generation + accumulate
 # is off on this path, so one flop = one lane-op.
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-PATH_STATE_BYTES = 44.0         # origin, direction, throughput (9 floats) + pixel + sample
-RAD_BYTES = 16.0                # one float4 per finished path, written once, read once
+PATH_STATE_BYTES = 44.0         # wavefront engine only: origin, direction, throughput (9 floats) + pixel + sample per queue slot
+RAD_BYTES = 16.0                # one float4 per finished path, written once (k_trace / k_bounce), read once (k_accumulate)
 
 
 def parse():
@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=128, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--engine", type=int, default=1, help="1: persistent k_trace (default), 0: wavefront k_bounce per depth")
     ap.add_argument("--ppm", default="", help="write the last image as ASCII PPM (outside the timed region)")
     return ap.parse_args()
 
@@ -73,6 +74,7 @@ def main():
     W, H, SPP = args.width, args.height, args.spp
     sc, cam = scene.cornell_box(W / H)
     ctx = capi.Context(local_rank)
+    ctx.set_option("engine", args.engine)
     ctx.upload_scene(sc)
     ctx.set_camera(cam)
     s_begin, s_count = sharding.spp_range(rank, world, SPP)
@@ -126,30 +128,41 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         msamples = samples / (dt / args.steps) / 1e6
         rays_per_sample = rays_total / samples_total
-        # dominant kernel = k_bounce at depth >= 1 (rank 0's launches, HIP events on their stream)
-        ext_rays = float(st.rays - st.samples)
-        ext_s = st.extend_ms * 1e-3
-        valu_achieved = ext_rays * FLOP_PER_RAY / ext_s / 1e12 if ext_s > 0 else 0.0
-        # queue traffic of those launches: each ray is read once; survivors (next depth's rays) are
-        # written once; a finished path writes its radiance once
+        # dominant kernel: k_trace (engine 1: one launch per batch, every bounce of every path) or k_bounce at
+        # depth >= 1 (engine 0); rank 0's launches, HIP events on their stream
         hist = list(st.depth_hist)
-        written = float(sum(hist[2:]))
-        finished = ext_rays - written
-        ext_bytes = ext_rays * PATH_STATE_BYTES + written * PATH_STATE_BYTES + finished * RAD_BYTES
-        hbm_achieved = ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0
+        launches = max(1, int(st.extend_launches))
+        k_s = st.extend_ms * 1e-3
+        if args.engine == 1:
+            kname = "k_trace<0,true>"
+            k_rays = float(st.rays)
+            k_flop = k_rays * FLOP_PER_RAY + float(st.samples) * FLOP_PER_SAMPLE_FIXED
+            k_bytes = float(st.samples) * RAD_BYTES                       # the only per-path HBM traffic: one radiance slot
+        else:
+            kname = "k_bounce<depth>=1>"
+            k_rays = float(st.rays - st.samples)
+            k_flop = k_rays * FLOP_PER_RAY
+            written = float(sum(hist[2:]))
+            k_bytes = k_rays * PATH_STATE_BYTES + written * PATH_STATE_BYTES + (k_rays - written) * RAD_BYTES
+        valu_achieved = k_flop / k_s / 1e12 if k_s > 0 else 0.0
+        hbm_achieved = k_bytes / k_s / 1e9 if k_s > 0 else 0.0
+        traffic = None
+        try:    # HBM bytes per launch from the committed PMC passes of this same workload (profiles/)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if pm.get("kernel") == kname and pm.get("paths_per_launch"):
+                traffic = round(pm["hbm_bytes_per_launch"] * (float(st.samples) / launches) / pm["paths_per_launch"], 1)
+        except (OSError, ValueError):
+            pass
+        common = {"kernel": kname, "launches": launches, "avg_launch_ms": round(st.extend_ms / launches, 4)}
         valu = {"bound": "valu", "achieved": round(valu_achieved, 4), "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s",
-                "frac": round(valu_achieved / VALU_PEAK_TOPS, 5), "traffic": None,
-                "kernel": "k_bounce<depth>=1>", "launches": int(st.extend_launches),
-                "avg_launch_ms": round(st.extend_ms / max(1, st.extend_launches), 4),
-                "flop_per_ray": FLOP_PER_RAY}
+                "frac": round(valu_achieved / VALU_PEAK_TOPS, 5), "traffic": traffic, **common,
+                "flop_per_ray": FLOP_PER_RAY, "flop_per_launch": round(k_flop / launches, 1)}
         hbm = {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": None,
-               "kernel": "k_bounce<depth>=1>", "launches": int(st.extend_launches),
-               "avg_launch_ms": round(st.extend_ms / max(1, st.extend_launches), 4),
-               "bytes_per_launch": round(ext_bytes / max(1, st.extend_launches), 1)}
-        # The bounce kernel is VALU-issue bound (profiles/: SQ_ACTIVE_INST_VALU ~ 80 % of SIMD cycles, HBM
-        # traffic = the algorithmic queue bytes), so the VALU roofline is the binding one; the HBM figure of
-        # the same launches is reported beside it.
+               "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic, **common,
+               "bytes_per_launch": round(k_bytes / launches, 1)}
+        # The kernel is VALU-issue bound (profiles/: VALU instructions x 2 cycles ~ 70 % of all SIMD cycles, HBM traffic
+        # a few GB per launch), so the VALU roofline is the binding one; the HBM figure of the same launches is beside it.
         roofline, other = valu, hbm
         out = {
             "metric": "Msamples/sec (whole node), Cornell box 3-ball 1024^2",
@@ -157,12 +170,12 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Cornell box 3-ball {W}x{H} @{SPP} spp, depth {args.max_depth}, spp-sharded over {world} GPU(s)",
-                       "seed": args.seed, "accel": "list (9 primitives in LDS)", "spp_per_gpu": s_count},
+                       "seed": args.seed, "accel": "list (9 primitives in LDS)", "spp_per_gpu": s_count,
+                       "engine": "persistent (k_trace)" if args.engine == 1 else "wavefront (k_bounce per depth)"},
             "mrays_per_s": round(msamples * rays_per_sample, 2), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": roofline, "roofline_other": other,
-            "whole_render": {"device_ms_rank0": round(st.device_ms, 3), "first_bounce_ms": round(st.first_ms, 3),
-                             "deeper_bounces_ms": round(st.extend_ms, 3), "batches": int(st.batches),
-                             "bounce_launches": int(st.bounce_launches)},
+            "whole_render": {"device_ms_rank0": round(st.device_ms, 3), "dominant_kernel_ms": round(st.extend_ms, 3),
+                             "batches": int(st.batches), "launches": int(st.bounce_launches)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, cam, W, H, args, ctx)

@@ -37,7 +37,7 @@ struct mirt_ctx {
     bool have_scene = false, have_camera = false;
     SceneDev sc{};                  // LDS plan for the list / reference-order walk (32-byte nodes)
     SceneDev sc2{};                 // LDS plan for the near-first walk (64-byte nodes)
-    uint32_t lds_bytes = 0, lds_bytes2 = 0;
+    uint32_t lds_bytes = 0, lds_bytes2 = 0, lds_stack_bytes = 0;   // the stack comes last in the plan: the list walk launches without it
     bool prims_in_lds = false;
     mirt_camera cam{};
     DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats;
@@ -46,9 +46,9 @@ struct mirt_ctx {
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
-    uint32_t lds_budget = 20u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
+    uint32_t lds_budget = 8u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
-    uint32_t stack_lds = 12;                // traversal-stack levels kept in LDS (1 KiB each); likewise
+    uint32_t stack_lds = 8;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
@@ -212,6 +212,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.node_bytes = (uint32_t)sizeof(NodeRec);
     d.lds_nodes = std::min<uint32_t>(room_bytes / d.node_bytes, d.n_nodes);
     c->lds_bytes = used + d.lds_nodes * d.node_bytes;
+    c->lds_stack_bytes = d.stack_lds * MIRT_BLOCK * 4u;
     c->sc2.node_bytes = (uint32_t)sizeof(Node2);
     c->sc2.lds_nodes = std::min<uint32_t>(room_bytes / c->sc2.node_bytes, d.n_nodes);
     c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
@@ -269,7 +270,7 @@ static int bind_spill(mirt_ctx *c, SceneDev &sd, uint32_t grid)
 template <bool FIRST>
 static void launch_bounce(const mirt_ctx *c, int mode, const BounceArgs &a, uint32_t grid, hipStream_t st)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     const bool pl = c->prims_in_lds;
     dim3 g(grid), b(MIRT_BLOCK);
     if (mode == 0) { if (pl) hipLaunchKernelGGL((k_bounce<FIRST, 0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_bounce<FIRST, 0, false>), g, b, lds, st, a); }
@@ -280,7 +281,7 @@ static void launch_bounce(const mirt_ctx *c, int mode, const BounceArgs &a, uint
 // Workgroups of the depth>=1 kernel that fit on one CU with this scene's LDS plan (the persistent grid is sized to it).
 static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     const bool pl = c->prims_in_lds;
     int n = 0;
     hipError_t e;
@@ -293,7 +294,7 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
 
 static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     const bool pl = c->prims_in_lds;
     dim3 g(grid), b(MIRT_BLOCK);
     if (mode == 0) { if (pl) hipLaunchKernelGGL((k_trace<0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<0, false>), g, b, lds, st, a); }
@@ -302,7 +303,7 @@ static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32
 }
 static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     const bool pl = c->prims_in_lds;
     int n = 0;
     hipError_t e;
@@ -341,6 +342,8 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     uint32_t batch = 0;
+    const bool timed = stats && c->time_launches;
+    if (timed) while (c->ev_pool.size() < 2 * (size_t)n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
     for (uint32_t pt = 0; pt < n_pix_tiles; ++pt) {
         const uint32_t pix0 = pt * npix_b;
         const uint32_t np = (uint32_t)std::min<uint64_t>(npix_b, npix_total - pix0);
@@ -353,7 +356,9 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             const uint64_t waves = (uint64_t)max_grid * (MIRT_BLOCK / 64);
             a.claim = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, max_grid);
+            if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch], st));
             launch_trace(c, mode, a, grid, st);
+            if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch + 1], st));
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
                                (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u);
         }
@@ -367,6 +372,10 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         HIPCHK(c, hipMemcpy(h.data(), counts, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         stats->device_ms = ms; stats->bounce_launches = n_batches; stats->batches = n_batches;
         stats->samples = npix_total * spp_count;
+        if (timed) for (uint32_t b = 0; b < n_batches; ++b) {          // k_trace launches are reported in the extend_* fields
+            float t = 0; HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[2 * b], c->ev_pool[2 * b + 1]));
+            stats->extend_ms += t; stats->extend_launches++;
+        }
         for (uint32_t b = 0; b < n_batches; ++b) {
             const uint32_t *hist = h.data() + b * per_batch + 1;
             uint64_t ended_at_or_after = 0;                      // paths that traced a ray at depth d = those ending at depth >= d
@@ -612,7 +621,7 @@ extern "C" int mirt_world_hit_batch(mirt_ctx *c, const float *org, const float *
     dim3 g((uint32_t)std::min<size_t>((nray + MIRT_BLOCK - 1) / MIRT_BLOCK, (size_t)c->n_cu * 16)), b(MIRT_BLOCK);
     const int mode = accel_mode(c, flags);
     const bool pl = c->prims_in_lds;
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : c->lds_bytes;
+    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     SceneDev sd = mode == 2 ? c->sc2 : c->sc;
     if (bind_spill(c, sd, g.x)) return fail(c, MIRT_ERR_NOMEM, "mirt_world_hit_batch: hipMalloc of the traversal-stack spill area failed");
     if (mode == 0) { if (pl) hipLaunchKernelGGL((k_world_hit_batch<0, true>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); else hipLaunchKernelGGL((k_world_hit_batch<0, false>), g, b, lds, 0, sd, dorg, ddir, (uint32_t)nray, t_min, t_max, dout); }
