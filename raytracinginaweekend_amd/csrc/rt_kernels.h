@@ -142,16 +142,71 @@ __device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
 // List: Hitables.cpp:130-142 semantics over every object in order (= every primitive in order):
 // t_max shrinks on each accepted hit, `<=` lets a later primitive win a tie.  All lanes walk the
 // same primitive, so the records are wave-uniform LDS broadcasts.
+// Two things are done differently from a literal walk, neither changes a bit of the result:
+//  * rect tests are specialised on the (wave-uniform) axis triple, so components are picked at compile time;
+//  * a sphere's roots (IEEE sqrt + one or two IEEE divides, ~50 instructions that only the few lanes whose
+//    line meets the sphere need) are deferred: the lane parks (-b, disc, index) and the roots are evaluated
+//    once after the loop -- or earlier, when a lane that already has a parked sphere meets another one.
+//    Which root is taken does not depend on t_max (the second root is never smaller than the first), and a
+//    parked sphere is accepted under the sequential rule "t <= t_max, later index wins a tie" restated with
+//    the index: t < t_max || (t == t_max && index > best).
+template <int A, int B, int C>
+__device__ __forceinline__ bool rect_t(const PrimRec &pr, f3 o, f3 d, float t_min, float t_max, float &t_out)
+{
+    const float oc = C == 0 ? o.x : (C == 1 ? o.y : o.z), dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
+    float t = (pr.gb[1] - oc) / dc;                                     // Hitables.cpp:95
+    if (t <= t_max && t >= t_min) {
+        const float oa = A == 0 ? o.x : (A == 1 ? o.y : o.z), da = A == 0 ? d.x : (A == 1 ? d.y : d.z);
+        const float ob = B == 0 ? o.x : (B == 1 ? o.y : o.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
+        float a = oa + t * da;
+        float b = ob + t * db;
+        if (a >= pr.ga[0] && a <= pr.ga[1] && b >= pr.ga[2] && b <= pr.gb[0]) { t_out = t; return true; }
+    }
+    return false;
+}
+
 template <bool PLDS>
 __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
                                                 float t_min, float &t_max)
 {
     int32_t best = -1;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
+    const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (spheres are never rotated)
+    bool pend = false; float p_nb = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;
+    auto resolve = [&]() {
+        if (pend) {
+            const float sq = __builtin_sqrtf(p_disc);
+            float t = (p_nb - sq) / two_a;                               // Hitables.cpp:31
+            if (!(t >= t_min)) t = (p_nb + sq) / two_a;                  // :41
+            if (t >= t_min && (t < t_max || (t == t_max && p_idx > best))) { t_max = t; best = p_idx; }
+            pend = false;
+        }
+    };
     for (uint32_t p = 0; p < sc.n_prims; ++p) {
+        const PrimRec &pr = P[p];
+        const uint32_t info = pr.info;
         float t;
-        if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+        bool hit;
+        if (PI_KIND(info) == MIRT_PRIM_SPHERE && !PI_ROT(info)) {
+            const f3 oc = o - mk(pr.off[0], pr.off[1], pr.off[2]);
+            const float b = 2.0f * dot(d, oc);
+            const float c = dot(oc, oc) - pr.ga[2];
+            const float disc = b * b - four_a * c;
+            const bool cross = disc > 0;
+            if (__ballot(cross && pend) != 0ull) resolve();
+            if (cross) { pend = true; p_nb = -b; p_disc = disc; p_idx = (int32_t)p; }
+            continue;
+        }
+        const uint32_t axes = (info >> 1) & 63u;                         // aAxis | bAxis << 2 | cAxis << 4
+        if (PI_KIND(info) != MIRT_PRIM_SPHERE && !PI_ROT(info) && (axes == (0u | 1u << 2 | 2u << 4) || axes == (0u | 2u << 2 | 1u << 4) || axes == (2u | 1u << 2 | 0u << 4))) {
+            const f3 ol = o - mk(pr.off[0], pr.off[1], pr.off[2]);
+            if (axes == (0u | 1u << 2 | 2u << 4)) hit = rect_t<0, 1, 2>(pr, ol, d, t_min, t_max, t);
+            else if (axes == (0u | 2u << 2 | 1u << 4)) hit = rect_t<0, 2, 1>(pr, ol, d, t_min, t_max, t);
+            else hit = rect_t<2, 1, 0>(pr, ol, d, t_min, t_max, t);
+        } else hit = prim_t(pr, o, d, t_min, t_max, t);
+        if (hit) { t_max = t; best = (int32_t)p; }
     }
+    resolve();
     return best;
 }
 
@@ -531,7 +586,7 @@ struct TraceArgs {
     uint32_t max_depth, flags, k0, k1;
 };
 #define MIRT_STASH 128
-struct StashLds { float ox[MIRT_STASH], oy[MIRT_STASH], oz[MIRT_STASH], dx[MIRT_STASH], dy[MIRT_STASH], dz[MIRT_STASH]; uint32_t id[MIRT_STASH]; };
+struct StashLds { float ox[MIRT_STASH], oy[MIRT_STASH], oz[MIRT_STASH], dx[MIRT_STASH], dy[MIRT_STASH], dz[MIRT_STASH]; uint32_t id[MIRT_STASH], sl[MIRT_STASH]; };
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -563,7 +618,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
     // the lane's path
     bool live = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
-    uint32_t pid = 0, depth = 0;
+    uint32_t pid = 0, pixel = 0, sample = 0, depth = 0;
 
     for (;;) {
         // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
@@ -584,7 +639,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
                     generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
                     const uint32_t e = cnt + lane;
                     stash.ox[e] = go.x; stash.oy[e] = go.y; stash.oz[e] = go.z;
-                    stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id;
+                    stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id; stash.sl[e] = sl;
                 }
                 w_next += g; cnt += g;
                 wave_lds_sync();
@@ -597,6 +652,8 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
             if (!live && rank < cnt) {
                 const uint32_t e = cnt - 1u - rank;
                 o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
+                const uint32_t sl = stash.sl[e];
+                sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
                 thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
             }
             const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -605,8 +662,6 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
         }
         if (__ballot(live) == 0ull) break;                          // pool exhausted, stash empty, every path ended
 
-        const uint32_t sl = pid / a.npix, pl = pid - sl * a.npix;
-        const uint32_t pixel = a.pix0 + pl, sample = a.spp0 + sl;
         // ---- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
         bool done = false;
         f3 radiance = mk(0.0f, 0.0f, 0.0f);
