@@ -1,5 +1,5 @@
 /*
- * mirt.h -- C ABI of the MI355X (gfx950) wavefront path tracer that replaces the render loop of
+ * mirt.h -- C ABI of the MI355X (gfx950) path tracer that replaces the render loop of
  * ByeDream/RayTracingInAWeekend's HomemadeRayTracer.
  *
  * The reference has no FFI: its seam is the C++ class HomemadeRayTracer
@@ -106,18 +106,19 @@ typedef struct mirt_render_params {
 } mirt_render_params;
 
 typedef struct mirt_stats {
-    uint64_t rays;               /* rays traced (sum of the per-bounce queue lengths)      */
+    uint64_t rays;               /* rays traced (exact: from the path-length histogram)    */
     uint64_t samples;            /* camera samples started                                 */
     uint64_t depth_hist[64];     /* rays per bounce index (0..63; deeper folded into 63)   */
     double   device_ms;          /* HIP-event time of the kernels of the call              */
     double   extend_ms;          /* with option time_launches=1: HIP-event time summed over the
-                                    depth>=1 bounce-kernel launches (the dominant kernel)   */
-    uint32_t bounce_launches;    /* number of bounce-kernel launches (all depths)          */
+                                    launches of the dominant kernel (engine 1: k_trace, one per
+                                    batch; engine 0: the depth>=1 k_bounce launches)        */
+    uint32_t bounce_launches;    /* number of tracing-kernel launches                      */
     uint32_t batches;
-    double   first_ms;           /* with time_launches=1: same for the depth-0 launches     */
-    uint32_t extend_launches;    /* depth>=1 launches timed into extend_ms                 */
+    double   first_ms;           /* engine 0 with time_launches=1: same for the depth-0 launches */
+    uint32_t extend_launches;    /* launches timed into extend_ms                          */
     uint32_t first_launches;
-    double   depth_ms[64];       /* with time_launches=1: launch time per bounce index      */
+    double   depth_ms[64];       /* engine 0 with time_launches=1: launch time per bounce index */
 } mirt_stats;
 
 typedef struct mirt_ctx mirt_ctx;
@@ -128,9 +129,16 @@ int         mirt_create(int device_id, mirt_ctx **out);
 void        mirt_destroy(mirt_ctx *ctx);                 /* HomemadeRayTracer::OnDestroy      */
 const char *mirt_last_error(const mirt_ctx *ctx);        /* ctx may be NULL: last create error */
 int         mirt_device_count(void);
-/* option names: "max_paths" (ray-queue capacity, default 256Mi paths;
- * queues are sized by the render at hand, up to this); "time_launches" (0/1:
- * bracket every bounce-kernel launch with HIP events and report the sums in mirt_stats) */
+/* option names:
+ *  "max_paths"      paths per batch (default 256 Mi; buffers are sized by the render at hand, up to this)
+ *  "time_launches"  0/1: bracket every tracing-kernel launch with HIP events, sums reported in mirt_stats
+ *  "engine"         1 (default): persistent kernel, one path per lane, no path queues;
+ *                   0: wavefront formulation, one launch per bounce over compacted path queues.
+ *                   Both produce the same bits.
+ *  "blocks_per_cu"  workgroups per CU of the persistent grid (0 = occupancy query, default)
+ *  "lds_budget", "stack_lds"  LDS plan of the next mirt_upload_scene: bytes per workgroup that the top of
+ *                   the BVH may fill (default 8192), traversal-stack levels kept in LDS (default 8, the
+ *                   rest spills to HBM) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 
 /* -- scene ---------------------------------------------------------------------------------- */
