@@ -246,3 +246,46 @@ def test_million_spheres(gpu, orc):
         g = gpu.render(w, h, 2, 50, 11, flags)
         H.assert_bits(g["sum"], osum, f"1M image flags={flags}")
         assert g["stats"].rays == ost.rays
+
+
+@pytest.mark.parametrize("world", list(WORLDS))
+def test_engines_identical(gpu, orc, world):
+    """The persistent engine (k_trace, default) and the wavefront engine (k_bounce per depth) run the same per-path
+    arithmetic with the same Philox keys: same bits, same ray counts per depth, under any batching."""
+    mk, w, h = WORLDS[world]
+    s, cam = mk()
+    s.nodes = None
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    out = {}
+    try:
+        for engine in (1, 0):
+            gpu.set_option("engine", engine)
+            for flags in (capi.FLAG_ACCEL_AUTO, capi.FLAG_ACCEL_LIST, 0):
+                out[engine, flags] = gpu.render(w, h, 5, 50, 77, flags)
+            gpu.set_option("max_paths", 2 * w * h + 3)                   # three sample tiles
+            out[engine, "tiled"] = gpu.render(w, h, 5, 50, 77, capi.FLAG_ACCEL_LIST)
+            gpu.set_option("max_paths", 256 << 20)
+    finally:
+        gpu.set_option("engine", 1); gpu.set_option("max_paths", 256 << 20)
+    osum, ost = orc.trace(s, cam, w, h, 5, 50, 77, capi.FLAG_ACCEL_LIST)
+    for key, g in out.items():
+        if world != "two_boxes" or key[1] in (capi.FLAG_ACCEL_LIST, "tiled"):   # coplanar ties: see test_ordered_traversal_and_own_bvh
+            H.assert_bits(g["sum"], osum, f"{world} {key}")
+            assert g["stats"].rays == ost.rays
+    for flags in (capi.FLAG_ACCEL_AUTO, capi.FLAG_ACCEL_LIST, 0, "tiled"):
+        a, b = out[1, flags], out[0, flags]
+        H.assert_bits(a["sum"], b["sum"], f"{world} engines {flags}")
+        assert list(a["stats"].depth_hist) == list(b["stats"].depth_hist) and a["stats"].rays == b["stats"].rays
+
+
+def test_persistent_engine_edges(gpu, orc):
+    """Path counts that are not multiples of the wave, of the claim size or of the stash; max_depth 0; one pixel."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    for (w, h, spp, md) in ((1, 1, 1, 50), (7, 3, 1, 50), (13, 5, 3, 2), (65, 1, 2, 0), (33, 31, 7, 50)):
+        g = gpu.render(w, h, spp, md, 5, capi.FLAG_ACCEL_LIST)
+        osum, ost = orc.trace(s, cam, w, h, spp, md, 5, capi.FLAG_ACCEL_LIST)
+        H.assert_bits(g["sum"], osum, f"{w}x{h}@{spp} depth {md}")
+        assert g["stats"].rays == ost.rays and g["stats"].samples == w * h * spp
+        hist = list(g["stats"].depth_hist)
+        assert hist[0] == w * h * spp and sum(hist) == ost.rays and all(a >= b for a, b in zip(hist, hist[1:])) and not any(hist[md + 1:])
