@@ -585,8 +585,11 @@ struct TraceArgs {
     uint32_t width, height, pix0, npix, spp0;
     uint32_t max_depth, flags, k0, k1;
 };
-#define MIRT_STASH 128
-struct StashLds { float ox[MIRT_STASH], oy[MIRT_STASH], oz[MIRT_STASH], dx[MIRT_STASH], dy[MIRT_STASH], dz[MIRT_STASH]; uint32_t id[MIRT_STASH], sl[MIRT_STASH]; };
+// 128 entries: topped up whenever fewer than 64 remain, so one pass always serves every idle lane (list walk:
+// the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
+// outnumber what is left (BVH walks: iterations are long, LDS is what limits residency).
+template <int N>
+struct StashLds { float ox[N], oy[N], oz[N], dx[N], dy[N], dz[N]; uint32_t id[N], sl[N]; };
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -600,7 +603,8 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
-    __shared__ StashLds s_stash[MIRT_BLOCK / 64];
+    constexpr bool BIG_STASH = ACCEL == 0;
+    __shared__ StashLds<BIG_STASH ? 128 : 64> s_stash[MIRT_BLOCK / 64];
     __shared__ uint32_t s_hist[65];
 
     if ((uint64_t)blockIdx.x * a.claim >= a.n_paths) return;        // more workgroups than claims (uniform)
@@ -608,7 +612,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
     if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
     lds_stage(a.sc, lv);                                            // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    StashLds &stash = s_stash[wave];
+    auto &stash = s_stash[wave];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // wave-uniform bookkeeping
@@ -621,44 +625,86 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
     uint32_t pid = 0, pixel = 0, sample = 0, depth = 0;
 
     for (;;) {
-        // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
-        if (cnt < 64u && !exhausted) {
-            if (w_next == w_end) {
-                uint32_t b = 0;
-                if (lane == 0) b = atomicAdd(a.cursor, a.claim);
-                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                if (b >= a.n_paths) exhausted = true;
-                else { w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim; }
-            }
-            if (!exhausted) {
-                const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
-                if (lane < g) {
-                    const uint32_t id = w_next + lane;
-                    const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
-                    f3 go, gd;
-                    generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
-                    const uint32_t e = cnt + lane;
-                    stash.ox[e] = go.x; stash.oy[e] = go.y; stash.oz[e] = go.z;
-                    stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id; stash.sl[e] = sl;
+        if constexpr (BIG_STASH) {
+            // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
+            if (cnt < 64u && !exhausted) {
+                if (w_next == w_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(a.cursor, a.claim);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    if (b >= a.n_paths) exhausted = true;
+                    else { w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim; }
                 }
-                w_next += g; cnt += g;
-                wave_lds_sync();
+                if (!exhausted) {
+                    const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
+                    if (lane < g) {
+                        const uint32_t id = w_next + lane;
+                        const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
+                        f3 go, gd;
+                        generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
+                        const uint32_t e = cnt + lane;
+                        stash.ox[e] = go.x; stash.oy[e] = go.y; stash.oz[e] = go.z;
+                        stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id; stash.sl[e] = sl;
+                    }
+                    w_next += g; cnt += g;
+                    wave_lds_sync();
+                }
             }
-        }
-        // ---- idle lanes take a fresh path from the top of the stash
-        const unsigned long long idle = __ballot(!live);
-        if (idle != 0ull && cnt != 0u) {
-            const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
-            if (!live && rank < cnt) {
-                const uint32_t e = cnt - 1u - rank;
-                o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
-                const uint32_t sl = stash.sl[e];
-                sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
-                thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
+            // ---- idle lanes take a fresh path from the top of the stash
+            const unsigned long long idle = __ballot(!live);
+            if (idle != 0ull && cnt != 0u) {
+                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                if (!live && rank < cnt) {
+                    const uint32_t e = cnt - 1u - rank;
+                    o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
+                    const uint32_t sl = stash.sl[e];
+                    sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
+                    thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
+                }
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                cnt -= (n_idle < cnt) ? n_idle : cnt;
+                wave_lds_sync();                                        // the freed entries are rewritten by the next top-up
             }
-            const uint32_t n_idle = (uint32_t)__popcll(idle);
-            cnt -= (n_idle < cnt) ? n_idle : cnt;
-            wave_lds_sync();                                        // the freed entries are rewritten by the next top-up
+        } else {
+            // ---- idle lanes take what the stash holds; if lanes are still idle, the whole wave makes 64 new
+            // camera rays (HomemadeRayTracer.cpp:114-131) into the now empty stash and serves the rest
+            const unsigned long long idle = __ballot(!live);
+            if (idle != 0ull && (cnt != 0u || !exhausted)) {
+                const uint32_t n_idle = (uint32_t)__popcll(idle);
+                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                uint32_t served = 0;
+                for (;;) {
+                    const uint32_t take = (n_idle - served < cnt) ? n_idle - served : cnt;
+                    if (!live && rank >= served && rank < served + take) {
+                        const uint32_t e = cnt - 1u - (rank - served);
+                        o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
+                        const uint32_t sl = stash.sl[e];
+                        sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
+                        thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
+                    }
+                    cnt -= take; served += take;
+                    wave_lds_sync();                                // entries read above may be rewritten below
+                    if (served == n_idle || exhausted) break;
+                    if (w_next == w_end) {
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(a.cursor, a.claim);
+                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                        if (b >= a.n_paths) { exhausted = true; break; }
+                        w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
+                    }
+                    const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
+                    if (lane < g) {
+                        const uint32_t id = w_next + lane;
+                        const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
+                        f3 go, gd;
+                        generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
+                        stash.ox[lane] = go.x; stash.oy[lane] = go.y; stash.oz[lane] = go.z;
+                        stash.dx[lane] = gd.x; stash.dy[lane] = gd.y; stash.dz[lane] = gd.z; stash.id[lane] = id; stash.sl[lane] = sl;
+                    }
+                    w_next += g; cnt = g;
+                    wave_lds_sync();
+                }
+            }
         }
         if (__ballot(live) == 0ull) break;                          // pool exhausted, stash empty, every path ended
 
