@@ -173,6 +173,14 @@ int mirt_resolve_device(mirt_ctx *ctx, const float *d_sum_rgb, uint32_t width, u
 int mirt_render(mirt_ctx *ctx, const mirt_render_params *p, float *h_sum_rgb, float *h_pixels,
                 uint8_t *h_rgba8, mirt_stats *stats);
 
+/* The interactive caller one step above TraceRay (the viewer re-invokes TraceRay from its paint
+ * loop, RayTracer.cpp:251-254): successive calls refine ONE image.  The radiance sum stays on the device between
+ * calls; a call with spp_begin == 0 restarts it, any other call must continue where the previous one ended on the
+ * same image size (else MIRT_ERR_STATE).  Outputs (each may be NULL) are the image of all samples so far; after
+ * calls covering [0,a) and [a,b) they equal, bit for bit, those of one mirt_render of [0,b). */
+int mirt_render_progressive(mirt_ctx *ctx, const mirt_render_params *p, float *h_sum_rgb, float *h_pixels_rgb,
+                            uint8_t *h_rgba8, mirt_stats *stats);
+
 /* -- function-level entry points (parity tests bind these; host pointers) -------------------- */
 /* AABB::Hit, AABB.cpp:5-21: out[i*nbox+b] = ray i vs box b */
 int mirt_aabb_hit_batch(mirt_ctx *ctx, const float *bmin, const float *bmax, size_t nbox,
@@ -205,6 +213,14 @@ int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y,
 /* -- host utilities -------------------------------------------------------------------------- */
 /* PPMImageMaker::OutputRGBA8ToFile, PPMImageMaker.cpp:9-48 (ASCII P3, alpha dropped) */
 int mirt_write_ppm(const char *path, uint32_t width, uint32_t height, const uint8_t *rgba8);
+/* Formats either side of the reference's P3 (PPMImageMaker.cpp:31-43 writes ~12 bytes of
+ * text per pixel, 200 MB at 4096^2).  P3/P6 take rgba8 (alpha dropped), PFM takes rgb_float: width*height*3
+ * floats, row 0 = top as everywhere in this ABI (e.g. the gamma-corrected pixels of mirt_resolve_device or
+ * the linear mean); the file is written bottom row first, little-endian ("PF", scale -1.0), as PFM defines. */
+#define MIRT_IMG_P3  0
+#define MIRT_IMG_P6  1
+#define MIRT_IMG_PFM 2
+int mirt_write_image(const char *path, int format, uint32_t width, uint32_t height, const uint8_t *rgba8, const float *rgb_float);
 
 #ifdef __cplusplus
 }

@@ -63,9 +63,9 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", 
 
 EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
-    "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render",
+    "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
-    "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_write_ppm",
+    "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_write_ppm", "mirt_write_image",
 ]
 
 _lib = None
@@ -97,6 +97,7 @@ def load():
     lib.mirt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.mirt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mirt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
+    lib.mirt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.mirt_aabb_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
     lib.mirt_prim_hit_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]
     lib.mirt_world_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, vp]
@@ -105,6 +106,7 @@ def load():
     lib.mirt_philox_batch.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.mirt_arith_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
     lib.mirt_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
+    lib.mirt_write_image.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
     for name in EXPORTS:
         if name not in ("mirt_destroy", "mirt_last_error"):
             getattr(lib, name).restype = C.c_int
@@ -175,6 +177,19 @@ class Context:
                                       _ptr(rg) if rg is not None else None, C.byref(st)), "mirt_render")
         out["sum"], out["pixels"], out["rgba8"], out["stats"] = s, px, rg, st
         return out
+
+    def render_progressive(self, width, height, spp_begin, spp_count, max_depth=50, seed=0x5EED, flags=FLAG_ACCEL_AUTO,
+                           want=("sum", "pixels", "rgba8")):
+        """mirt_render_progressive: adds samples [spp_begin, spp_begin+spp_count) to the image kept on the device."""
+        p = RenderParams(width, height, spp_begin, spp_count, max_depth, flags, seed)
+        s = np.empty((height, width, 3), np.float32) if "sum" in want else None
+        px = np.empty((height, width, 3), np.float32) if "pixels" in want else None
+        rg = np.empty((height, width, 4), np.uint8) if "rgba8" in want else None
+        st = Stats()
+        self._ck(self.lib.mirt_render_progressive(self.h, C.byref(p), _ptr(s) if s is not None else None,
+                                                  _ptr(px) if px is not None else None,
+                                                  _ptr(rg) if rg is not None else None, C.byref(st)), "mirt_render_progressive")
+        return {"sum": s, "pixels": px, "rgba8": rg, "stats": st}
 
     def render_device(self, params, d_sum_ptr, stream=None, stats=None):
         self._ck(self.lib.mirt_render_device(self.h, C.byref(params), C.c_void_p(d_sum_ptr),
@@ -252,6 +267,19 @@ def build_bvh(scene):
         raise MirtError(f"mirt_build_bvh failed ({rc})")
     scene.set_bvh(mn[:n.value], mx[:n.value], l[:n.value], r[:n.value], root.value)
     return depth.value
+
+
+IMG_P3, IMG_P6, IMG_PFM = 0, 1, 2
+
+
+def write_image(path, fmt, rgba8=None, rgb_float=None):
+    """mirt_write_image: ASCII P3 / binary P6 from RGBA8, PFM from float RGB (row 0 = top on input)."""
+    a = np.ascontiguousarray(rgba8, np.uint8) if rgba8 is not None else None
+    f = np.ascontiguousarray(rgb_float, np.float32) if rgb_float is not None else None
+    h, w = (a if a is not None else f).shape[:2]
+    rc = load().mirt_write_image(os.fsencode(path), fmt, w, h, _ptr(a) if a is not None else None, _ptr(f) if f is not None else None)
+    if rc != 0:
+        raise MirtError(f"mirt_write_image failed ({rc})")
 
 
 def write_ppm(path, rgba8):

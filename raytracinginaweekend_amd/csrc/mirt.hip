@@ -42,6 +42,8 @@ struct mirt_ctx {
     mirt_camera cam{};
     DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats;
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
+    DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
+    uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
@@ -95,7 +97,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_spill, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -561,6 +563,38 @@ extern "C" int mirt_render(mirt_ctx *c, const mirt_render_params *p, float *h_su
     return MIRT_OK;
 }
 
+// Progressive form of mirt_render for the interactive caller (the viewer loop of RayTracer.cpp:251-254 re-invokes
+// TraceRay; here successive calls refine one image): the sum stays on the device between calls.
+extern "C" int mirt_render_progressive(mirt_ctx *c, const mirt_render_params *p, float *h_sum, float *h_pixels, uint8_t *h_rgba8, mirt_stats *stats)
+{
+    if (!c || !p) return MIRT_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)p->width * p->height;
+    if (!npix) return fail(c, MIRT_ERR_ARG, "mirt_render_progressive: empty image");
+    if (p->flags & MIRT_FLAG_ONE_SPP) return fail(c, MIRT_ERR_ARG, "mirt_render_progressive: MIRT_FLAG_ONE_SPP has nothing to accumulate (use mirt_render)");
+    if (p->spp_begin == 0) {
+        if (c->d_prog_sum.ensure(npix * 3 * sizeof(float))) return fail(c, MIRT_ERR_NOMEM, "mirt_render_progressive: hipMalloc failed");
+        HIPCHK(c, hipMemset(c->d_prog_sum.p, 0, npix * 3 * sizeof(float)));
+        c->prog_w = p->width; c->prog_h = p->height; c->prog_spp = 0;
+    } else if (p->width != c->prog_w || p->height != c->prog_h || p->spp_begin != c->prog_spp) {
+        return fail(c, MIRT_ERR_STATE, "mirt_render_progressive: spp_begin must continue the previous call on the same image size (or be 0 to restart)");
+    }
+    if ((uint64_t)p->spp_begin + p->spp_count > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_progressive: sample index overflows 32 bits");
+    if (c->d_tmp_pix.ensure(npix * 3 * sizeof(float)) || c->d_tmp_rgba.ensure(npix * 4)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_progressive: hipMalloc failed");
+    int rc = mirt_render_device(c, p, (float *)c->d_prog_sum.p, nullptr, stats);
+    if (rc) return rc;
+    c->prog_spp = p->spp_begin + p->spp_count;
+    if (c->prog_spp == 0) return MIRT_OK;
+    rc = mirt_resolve_device(c, (const float *)c->d_prog_sum.p, p->width, p->height, c->prog_spp, p->flags,
+                             (float *)c->d_tmp_pix.p, (uint8_t *)c->d_tmp_rgba.p, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (h_sum) HIPCHK(c, hipMemcpy(h_sum, c->d_prog_sum.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_pixels) HIPCHK(c, hipMemcpy(h_pixels, c->d_tmp_pix.p, npix * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_rgba8) HIPCHK(c, hipMemcpy(h_rgba8, c->d_tmp_rgba.p, npix * 4, hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
 // ------------------------------------------------------------------------------------------ function-level entry points
 namespace {
 struct Tmp {   // RAII device scratch for the batch hooks
@@ -724,4 +758,31 @@ extern "C" int mirt_write_ppm(const char *path, uint32_t width, uint32_t height,
     }
     fwrite(buf.data(), 1, buf.size(), f);
     return fclose(f) == 0 ? MIRT_OK : MIRT_ERR_ARG;
+}
+
+extern "C" int mirt_write_image(const char *path, int format, uint32_t width, uint32_t height, const uint8_t *rgba8, const float *rgb_float)
+{
+    if (!path || !width || !height) return MIRT_ERR_ARG;
+    if (format == MIRT_IMG_P3) return mirt_write_ppm(path, width, height, rgba8);
+    if (format != MIRT_IMG_P6 && format != MIRT_IMG_PFM) return MIRT_ERR_ARG;
+    if (format == MIRT_IMG_P6 ? !rgba8 : !rgb_float) return MIRT_ERR_ARG;
+    FILE *f = fopen(path, "wb");
+    if (!f) return MIRT_ERR_ARG;
+    bool ok = true;
+    if (format == MIRT_IMG_P6) {
+        ok = fprintf(f, "P6\n%u %u\n255\n", width, height) > 0;
+        std::vector<uint8_t> row(3 * (size_t)width);
+        for (uint32_t y = 0; y < height && ok; ++y) {
+            const uint8_t *src = rgba8 + 4 * (size_t)y * width;
+            for (uint32_t x = 0; x < width; ++x) { row[3 * x] = src[4 * x]; row[3 * x + 1] = src[4 * x + 1]; row[3 * x + 2] = src[4 * x + 2]; }
+            ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+        }
+    } else {
+        const uint16_t probe = 1;
+        if (*(const uint8_t *)&probe != 1) { fclose(f); return MIRT_ERR_ARG; }          // little-endian hosts only
+        ok = fprintf(f, "PF\n%u %u\n-1.0\n", width, height) > 0;
+        for (uint32_t y = height; y-- > 0 && ok;)
+            ok = fwrite(rgb_float + 3 * (size_t)y * width, sizeof(float), 3 * (size_t)width, f) == 3 * (size_t)width;
+    }
+    return (fclose(f) == 0 && ok) ? MIRT_OK : MIRT_ERR_ARG;
 }

@@ -20,6 +20,10 @@ public:
 	void OnDestroy();
 	void HelpInfo();
 	void TraceRay(const SimpleCamera *camera, OutputImage *image);
+	// Progressive form for the interactive caller: adds samples [firstSample, firstSample + sampleCount) to the image
+	// kept on the device (firstSample == 0 restarts it) and renders the mean of all samples so far into `image`.
+	// After passes [0,a) and [a,b) the image equals that of one TraceRay with b samples.
+	void TraceRayProgressive(const SimpleCamera *camera, OutputImage *image, UINT32 firstSample, UINT32 sampleCount);
 
 	// SAMPLE_PER_PIXEL / MAX_SAMPLE_DEPTH (reference HomemadeRayTracer.cpp:21-22) at run time, plus what
 	// the reference cannot express: a seed, the GPU to use, and the toggles without key events
@@ -42,4 +46,5 @@ private:
 	mirt_ctx      *m_ctx{ nullptr };
 	const World   *m_uploadedWorld{ nullptr };
 	mirt_stats     m_stats{};
+	void Prepare(const SimpleCamera *camera);        // context, scene upload (once per world), camera
 };

@@ -14,6 +14,7 @@ public:
 	void RenderAsRed();
 	void Render(const Vec3 *pixels, UINT32 pixelCount = 0);
 	void Output();                                   // <name>.ppm through PPMImageMaker
+	void OutputBinary();                             // not in the reference: <name>.ppm as binary P6
 
 	UINT32      m_width{ 0 };
 	UINT32      m_height{ 0 };

@@ -16,6 +16,7 @@ public:
 	void OnUpdate(float elapsedSeconds);
 	void HelpInfo();
 	void Export(mirt_camera &out) const;
+	BOOL AutoFocus(const Vec3 &lookDir);             // SimpleCamera.cpp:202-214: focus on what the view axis hits
 
 private:
 	void Reset();

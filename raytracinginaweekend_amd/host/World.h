@@ -2,6 +2,9 @@
 #pragma once
 #include "stdafx.h"
 #include "FlatScene.h"
+#include "Ray.h"
+
+struct mirt_ctx;
 
 class Resources;
 class SimpleCamera;
@@ -35,10 +38,18 @@ public:
 
 	void Flatten(FlatScene &out) const;
 
+	// What SimpleCamera::AutoFocus asks of GetObjectBVHTree()->Hit (SimpleCamera.cpp:202-214): the closest hit of
+	// one ray.  Hit() exists only on the device, so this is a one-ray mirt_world_hit_batch on a context the world
+	// keeps for such queries (the tree is walked in the reference's order).  Throws without a GPU.
+	BOOL ClosestHit(const Ray &r, float tMin, float tMax, Vec3 &position) const;
+	void SetQueryDevice(int device) { m_queryDevice = device; }
+
 private:
 	Resources           *m_resources{ nullptr };
 	SimpleObjectBVHNode *m_objectBVHTree{ nullptr };
 	size_t               m_objectsCount{ 0 };
 	std::vector<class Object *> m_objects;            // construction order (owned by the tree)
 	LightSources        *m_lightSources{ nullptr };
+	mutable mirt_ctx    *m_queryCtx{ nullptr };
+	int                  m_queryDevice{ 0 };
 };

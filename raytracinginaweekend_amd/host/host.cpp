@@ -450,6 +450,7 @@ void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // Worl
 }
 void World::DeconstructWorld()
 {
+	if (m_queryCtx) { mirt_destroy(m_queryCtx); m_queryCtx = nullptr; }
 	delete m_objectBVHTree; m_objectBVHTree = nullptr; m_objects.clear();
 	delete m_lightSources; m_lightSources = nullptr;
 	if (m_resources) { m_resources->Unload(); delete m_resources; m_resources = nullptr; }
@@ -461,6 +462,24 @@ void World::Flatten(FlatScene &out) const
 	out.root = m_objectBVHTree->Flatten(out);
 	Vec3 amb = m_lightSources->GetAmbientLight();
 	for (int i = 0; i < 3; ++i) out.ambient[i] = amb[i];
+}
+
+BOOL World::ClosestHit(const Ray &r, float tMin, float tMax, Vec3 &position) const
+{
+	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_queryCtx)); };
+	if (!m_queryCtx) {
+		check(mirt_create(m_queryDevice, &m_queryCtx), "mirt_create");
+		FlatScene flat;
+		Flatten(flat);
+		mirt_scene view = flat.View();
+		check(mirt_upload_scene(m_queryCtx, &view), "mirt_upload_scene");
+	}
+	const float org[3] = { r.m_org[0], r.m_org[1], r.m_org[2] }, dir[3] = { r.m_dir[0], r.m_dir[1], r.m_dir[2] };
+	mirt_hit hit;
+	check(mirt_world_hit_batch(m_queryCtx, org, dir, 1, tMin, tMax, 0u, &hit), "mirt_world_hit_batch");
+	if (hit.prim < 0) return FALSE;
+	position = Vec3(hit.pos[0], hit.pos[1], hit.pos[2]);
+	return TRUE;
 }
 
 // =========================================================================================== InputListener
@@ -524,10 +543,42 @@ void SimpleCamera::InternalUpdate()                                      // Simp
 	m_viewHorizontal = 2.0f * halfW * m_u;
 	m_viewVertical = -2.0f * halfH * m_v;
 }
-void SimpleCamera::OnUpdate(float)
+void SimpleCamera::OnUpdate(float elapsedSeconds)                        // SimpleCamera.cpp:62-124
 {
-	if (m_inputListener && m_inputListener->WhenReleaseKey(VK_ESCAPE)) Reset();   // the fly controls are interactive-only
-	if (m_inputListener && m_inputListener->WhenReleaseKey('H')) HelpInfo();
+	if (!m_inputListener) return;
+	if (m_inputListener->WhenReleaseKey(VK_ESCAPE)) { Reset(); return; }
+	const BOOL holdA = m_inputListener->WhenHoldKey('A'), holdD = m_inputListener->WhenHoldKey('D');
+	const BOOL holdW = m_inputListener->WhenHoldKey('W'), holdS = m_inputListener->WhenHoldKey('S');
+	const BOOL holdLeft = m_inputListener->WhenHoldKey(VK_LEFT), holdRight = m_inputListener->WhenHoldKey(VK_RIGHT);
+	const BOOL holdUp = m_inputListener->WhenHoldKey(VK_UP), holdDown = m_inputListener->WhenHoldKey(VK_DOWN);
+	const BOOL holdAnyKey = holdA || holdD || holdW || holdS || holdLeft || holdRight || holdUp || holdDown;
+	Vec3 move(0.0f, 0.0f, 0.0f);
+	if (holdA) move += Vec3(-1.0f, 0.0f, 0.0f);
+	if (holdD) move += Vec3(1.0f, 0.0f, 0.0f);
+	if (holdW) move += Vec3(0.0f, 0.0f, -1.0f);
+	if (holdS) move += Vec3(0.0f, 0.0f, 1.0f);
+	if (holdLeft) m_yaw += m_turnSpeed * elapsedSeconds;
+	if (holdRight) m_yaw -= m_turnSpeed * elapsedSeconds;
+	if (holdUp) m_pitch -= m_turnSpeed * elapsedSeconds;
+	if (holdDown) m_pitch += m_turnSpeed * elapsedSeconds;
+	if (holdAnyKey) {
+		move.normalize();
+		move *= m_moveSpeed * elapsedSeconds;
+		Vec3 offset = m_u * move.x() + m_w * move.z();
+		m_origin += offset;
+		float r = cosf(m_pitch);
+		Vec3 lookDir(r * sinf(m_yaw), -sinf(m_pitch), r * cosf(m_yaw));
+		m_focus = m_origin + lookDir;
+		AutoFocus(lookDir);
+		InternalUpdate();
+	}
+	if (m_inputListener->WhenReleaseKey('H')) HelpInfo();
+}
+BOOL SimpleCamera::AutoFocus(const Vec3 &lookDir)                        // SimpleCamera.cpp:202-214
+{
+	Vec3 pos;
+	if (m_world && m_world->ClosestHit(Ray(m_origin, lookDir), 0.01f, FLT_MAX, pos)) m_focus = pos;
+	return TRUE;
 }
 void SimpleCamera::HelpInfo()
 {
@@ -588,6 +639,17 @@ void PPMImageMaker::OutputRGBA8ToFile(const char *fileName, UINT32 w, UINT32 h, 
 	if (mirt_write_ppm(fileName, w, h, rgba8) != MIRT_OK) throw std::runtime_error(std::string("PPMImageMaker: cannot write ") + fileName);
 	cout << "[PPMImageMaker] Done" << endl;
 }
+void OutputImage::OutputBinary()
+{
+	std::string path = m_outputDir + "/" + m_name + ".ppm";
+	PPMImageMaker::OutputRGBA8ToBinaryFile(path.c_str(), m_width, m_height, m_data, m_dataSizeInByte);
+}
+void PPMImageMaker::OutputRGBA8ToBinaryFile(const char *fileName, UINT32 w, UINT32 h, const UINT8 *rgba8, UINT64 dataSizeInByte)
+{
+	if (!rgba8) throw std::invalid_argument("PPMImageMaker: invalid data ptr");
+	if (dataSizeInByte && dataSizeInByte != (UINT64)w * h * 4) throw std::invalid_argument("PPMImageMaker: unmatching image size and data size");
+	if (mirt_write_image(fileName, MIRT_IMG_P6, w, h, rgba8, nullptr) != MIRT_OK) throw std::runtime_error(std::string("PPMImageMaker: cannot write ") + fileName);
+}
 
 // =========================================================================================== HomemadeRayTracer
 HomemadeRayTracer::HomemadeRayTracer(InputListener *inputListener, OutputImage *, const World *world) : m_inputListener(inputListener), m_world(world) {}
@@ -613,11 +675,8 @@ void HomemadeRayTracer::HelpInfo()
 	     << "[NormalDisplay] " << (m_enableNormalDisplay ? "Enabled" : "Disabled") << "  [1SPP] " << (m_enable1SPP ? "Enabled" : "Disabled")
 	     << "  [SPP] " << m_spp << "  [depth] " << m_maxDepth << endl;
 }
-void HomemadeRayTracer::TraceRay(const SimpleCamera *camera, OutputImage *image)   // HomemadeRayTracer.cpp:90-154
+void HomemadeRayTracer::Prepare(const SimpleCamera *camera)
 {
-	if (!camera || !image || !m_world) throw std::invalid_argument("HomemadeRayTracer::TraceRay: null argument");
-	cout << "[HomemadeRayTracer] TraceRay ..." << endl;
-	cout << "[HomemadeRayTracer] SPP: " << (m_enable1SPP ? 1u : m_spp) << endl;
 	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_ctx)); };
 	if (!m_ctx) check(mirt_create(m_device, &m_ctx), "mirt_create");
 	if (m_uploadedWorld != m_world) {
@@ -629,6 +688,25 @@ void HomemadeRayTracer::TraceRay(const SimpleCamera *camera, OutputImage *image)
 	}
 	mirt_camera cam; camera->Export(cam);
 	check(mirt_set_camera(m_ctx, &cam), "mirt_set_camera");
+}
+void HomemadeRayTracer::TraceRayProgressive(const SimpleCamera *camera, OutputImage *image, UINT32 firstSample, UINT32 sampleCount)
+{
+	if (!camera || !image || !m_world) throw std::invalid_argument("HomemadeRayTracer::TraceRayProgressive: null argument");
+	Prepare(camera);
+	mirt_render_params p{};
+	p.width = image->m_width; p.height = image->m_height; p.spp_begin = firstSample; p.spp_count = sampleCount; p.max_depth = m_maxDepth; p.seed = m_seed;
+	p.flags = MIRT_FLAG_ACCEL_AUTO | (m_enableNormalDisplay ? MIRT_FLAG_NORMAL_DISPLAY : 0u);
+	if (mirt_render_progressive(m_ctx, &p, nullptr, nullptr, image->m_data, &m_stats) != MIRT_OK)
+		throw std::runtime_error(std::string("mirt_render_progressive: ") + mirt_last_error(m_ctx));
+	image->m_isDirty = TRUE;
+}
+void HomemadeRayTracer::TraceRay(const SimpleCamera *camera, OutputImage *image)   // HomemadeRayTracer.cpp:90-154
+{
+	if (!camera || !image || !m_world) throw std::invalid_argument("HomemadeRayTracer::TraceRay: null argument");
+	cout << "[HomemadeRayTracer] TraceRay ..." << endl;
+	cout << "[HomemadeRayTracer] SPP: " << (m_enable1SPP ? 1u : m_spp) << endl;
+	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_ctx)); };
+	Prepare(camera);
 	mirt_render_params p{};
 	p.width = image->m_width; p.height = image->m_height; p.spp_begin = 0; p.spp_count = m_spp; p.max_depth = m_maxDepth; p.seed = m_seed;
 	p.flags = MIRT_FLAG_ACCEL_AUTO | (m_enable1SPP ? MIRT_FLAG_ONE_SPP : 0u) | (m_enableNormalDisplay ? MIRT_FLAG_NORMAL_DISPLAY : 0u);
@@ -659,6 +737,27 @@ const mirt_scene *mirt_host_world_scene(const mirt_host_world *h) { return &h->v
 const mirt_camera *mirt_host_world_camera(const mirt_host_world *h) { return &h->mcam; }
 void mirt_host_world_destroy(mirt_host_world *h) { if (!h) return; h->world.DeconstructWorld(); delete h->cam; delete h; }
 // whole reference flow: ConstructWorld -> TraceRay -> image bytes (and optionally <dir>/<name>.ppm)
+// scripted fly-through of the camera: frame f holds the (up to 4) key codes keys[4*f..4*f+3] (0 = none) for dt
+// seconds, then the camera is exported.  AutoFocus runs on the GPU.
+int mirt_host_camera_script(int world_id, float aspect, uint64_t scene_seed, const uint8_t *keys, uint32_t n_frames, float dt,
+                            mirt_camera *out_per_frame, char *err, size_t errlen)
+{
+	try {
+		InputListener input; World world;
+		Randomizer::Seed(scene_seed);
+		SimpleCamera camera(&world, &input, aspect);
+		world.ConstructWorld((WorldID)world_id, &camera);
+		for (uint32_t f = 0; f < n_frames; ++f) {
+			for (int k = 0; k < 4; ++k) if (keys[4 * f + k]) { input.NotifyKeyDown(keys[4 * f + k]); input.NotifyKeyDown(keys[4 * f + k]); }   // press, then the auto-repeat that means "hold" (InputListener.cpp:48-59)
+			camera.OnUpdate(dt);
+			for (int k = 0; k < 4; ++k) if (keys[4 * f + k]) input.NotifyKeyUp(keys[4 * f + k]);
+			input.Clear();
+			camera.Export(out_per_frame[f]);
+		}
+		world.DeconstructWorld();
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
 int mirt_host_render(int world_id, uint32_t w, uint32_t h, uint32_t spp, uint32_t depth, uint64_t scene_seed, uint64_t seed, int one_spp, int normal,
                      uint8_t *rgba8_out, const char *ppm_dir, char *err, size_t errlen)
 {

@@ -62,3 +62,23 @@ def render(world_id, w, h, spp, depth=50, scene_seed=1, seed=0x5EED, one_spp=Fal
     if rc != 0:
         raise RuntimeError(err.value.decode())
     return out
+
+
+KEY = {"W": ord("W"), "A": ord("A"), "S": ord("S"), "D": ord("D"), "L": 0x25, "U": 0x26, "R": 0x27, "P": 0x28}
+
+
+def camera_script(world_id, aspect, scene_seed, frames, dt):
+    """frames: list of strings of keys from KEY held during that frame -> one CameraStruct per frame."""
+    L = lib()
+    L.mirt_host_camera_script.argtypes = [C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mirt_host_camera_script.restype = C.c_int
+    keys = np.zeros((len(frames), 4), np.uint8)
+    for f, held in enumerate(frames):
+        for k, ch in enumerate(held):
+            keys[f, k] = KEY[ch]
+    out = (capi.CameraStruct * len(frames))()
+    err = C.create_string_buffer(512)
+    rc = L.mirt_host_camera_script(world_id, aspect, scene_seed, keys.ctypes.data_as(C.c_void_p), len(frames), dt, C.cast(out, C.c_void_p), err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    return [np.frombuffer(bytes(c), np.float32).copy() for c in out]

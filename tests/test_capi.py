@@ -118,3 +118,26 @@ def test_own_bvh_builder_makes_valid_trees():
         H.assert_bits(a["t"], b["t"], "own tree vs list")
         if s.n_objects > 100:
             assert sa.prims_tested < 0.05 * sb.prims_tested            # the tree prunes
+
+
+def test_image_writers(tmp_path):
+    """P3 is the reference's format (PPMImageMaker.cpp:31-43); P6 and PFM carry the same pixels."""
+    rng = np.random.default_rng(3)
+    w, h = 7, 5
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    flt = rng.normal(size=(h, w, 3)).astype(np.float32)
+    p3, p6, pfm = (str(tmp_path / n) for n in ("a.ppm", "b.ppm", "c.pfm"))
+    capi.write_image(p3, capi.IMG_P3, rgba8=rgba); capi.write_image(p6, capi.IMG_P6, rgba8=rgba); capi.write_image(pfm, capi.IMG_PFM, rgb_float=flt)
+    tok = open(p3).read().split()
+    assert tok[:4] == ["P3", str(w), str(h), "255"] and np.array_equal(np.array(tok[4:], np.uint8).reshape(h, w, 3), rgba[..., :3])
+    raw = open(p6, "rb").read()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    assert raw.startswith(head) and np.array_equal(np.frombuffer(raw[len(head):], np.uint8).reshape(h, w, 3), rgba[..., :3])
+    raw = open(pfm, "rb").read()
+    head = f"PF\n{w} {h}\n-1.0\n".encode()
+    assert raw.startswith(head)
+    assert np.array_equal(np.frombuffer(raw[len(head):], "<f4").reshape(h, w, 3)[::-1], flt)      # PFM stores the bottom row first
+    with pytest.raises(capi.MirtError):
+        capi.write_image(str(tmp_path / "d.pfm"), capi.IMG_PFM, rgba8=rgba)                        # PFM needs floats
+    with pytest.raises(capi.MirtError):
+        capi.write_image(str(tmp_path / "nodir" / "e.ppm"), capi.IMG_P6, rgba8=rgba)

@@ -90,3 +90,79 @@ def test_example_program_renders_a_ppm(tmp_path):
     assert "[HomemadeRayTracer] SPP: 4" in r.stdout
     lines = open(tmp_path / "OutputImage.ppm").read().split("\n")
     assert lines[1] == "64 64" and len(lines) == 3 + 64 * 64 + 1
+
+
+@pytest.mark.gpu
+def test_fly_camera_and_autofocus(orc):
+    """SimpleCamera::OnUpdate (SimpleCamera.cpp:62-124) with AutoFocus (:202-214) answered by the device: the camera
+    after each scripted frame equals a float32 restatement whose focus ray is traced by the oracle."""
+    F = np.float32
+    frames, dt = ["W", "WL", "L", "D", "", "SU", "P", "AR"], 1.0 / 30.0
+    for wid, look_from, look_at, fov, aperture, aspect in ((hostapi.WORLD_CORNELL, (0.0, 0.64, 4.63), (0.0, -0.26, -1.0), 30.0, 0.0, 1.0),
+                                                            (hostapi.WORLD_FOUR_SPHERES, (11.0, 2.0, 3.0), (0.0, 0.6, 0.0), 20.0, 0.1, 2.0)):
+        got = hostapi.camera_script(wid, aspect, 1, frames, dt)
+        hs, _ = hostapi.build_world(wid, aspect, seed=1)
+        origin, focus = np.array(look_from, F), np.array(look_at, F)
+        look = focus - origin
+        ln = np.sqrt((look * look).sum(dtype=F))
+        pitch = F(-np.arcsin(look[1] / ln))
+        yaw = F(np.arctan(look[0] / look[2]) + (np.pi if look[2] < 0 else 0.0))
+        move_speed, turn_speed = F(10.0), F(1.0)
+        for f, held in enumerate(frames):
+            if held:
+                cam = np.frombuffer(bytes(scene.make_camera(origin, focus, fov, aperture, aspect)), F)
+                u = cam[12:15]
+                w = (origin - focus) / np.sqrt(((origin - focus) ** 2).sum(dtype=F))
+                move = np.zeros(3, F)
+                for ch, v in (("A", (-1, 0, 0)), ("D", (1, 0, 0)), ("W", (0, 0, -1)), ("S", (0, 0, 1))):
+                    if ch in held:
+                        move += np.array(v, F)
+                yaw += F(turn_speed * F(dt)) * (("L" in held) - ("R" in held))
+                pitch += F(turn_speed * F(dt)) * (("P" in held) - ("U" in held))
+                n = np.sqrt((move * move).sum(dtype=F))
+                move = (move / n if n > 0 else move) * F(move_speed * F(dt))
+                origin = origin + (u * move[0] + w * move[2])
+                r = np.cos(pitch)
+                look_dir = np.array([r * np.sin(yaw), -np.sin(pitch), r * np.cos(yaw)], F)
+                focus = origin + look_dir
+                hit, _ = orc.world_hit_batch(hs, origin[None], look_dir[None], 0.01, float(np.finfo(F).max), 0)
+                if hit["prim"][0] >= 0:
+                    focus = hit["pos"][0].astype(F)
+            exp = np.frombuffer(bytes(scene.make_camera(origin, focus, fov, aperture, aspect)), F)
+            assert np.allclose(got[f], exp, rtol=2e-4, atol=2e-4), (wid, f, got[f], exp)
+    assert not np.allclose(got[0], got[-1], atol=1e-3)                   # the script really moved the camera
+
+
+@pytest.mark.gpu
+def test_progressive_passes_equal_one_render(gpu):
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w, h = 80, 60
+    one = gpu.render(w, h, 11, 50, 9)
+    a = gpu.render_progressive(w, h, 0, 4, 50, 9)
+    assert np.array_equal(a["rgba8"], gpu.render(w, h, 4, 50, 9)["rgba8"])
+    b = gpu.render_progressive(w, h, 4, 1, 50, 9)
+    c = gpu.render_progressive(w, h, 5, 6, 50, 9)
+    H.assert_bits(c["sum"], one["sum"], "progressive sum"); H.assert_bits(c["pixels"], one["pixels"], "progressive pixels")
+    assert np.array_equal(c["rgba8"], one["rgba8"]) and not np.array_equal(b["rgba8"], one["rgba8"])
+    with pytest.raises(capi.MirtError, match="continue"):
+        gpu.render_progressive(w, h, 5, 2, 50, 9)                        # [5,7) does not continue [0,11)
+    with pytest.raises(capi.MirtError, match="continue"):
+        gpu.render_progressive(w + 1, h, 11, 2, 50, 9)
+    with pytest.raises(capi.MirtError):
+        gpu.render_progressive(w, h, 0, 2, 50, 9, flags=capi.FLAG_ONE_SPP)
+    d = gpu.render_progressive(w, h, 0, 11, 50, 9)                       # restart
+    assert np.array_equal(d["rgba8"], one["rgba8"])
+
+
+@pytest.mark.gpu
+def test_flythrough_cli(tmp_path):
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "flythrough")
+    r = subprocess.run([exe, "1", "48", "40", "3", "6", "4", str(tmp_path), "W,WL,-"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    names = sorted(os.listdir(tmp_path))
+    assert names == ["preview_0000.ppm", "preview_0001.ppm", "preview_0002.ppm", "refine_00004.ppm", "refine_00006.ppm"]
+    frames = [open(tmp_path / n, "rb").read() for n in names]
+    assert all(f.startswith(b"P6\n48 40\n255\n") and len(f) == 13 + 48 * 40 * 3 for f in frames)
+    assert frames[0] != frames[1] and frames[3] != frames[4]             # the camera moved; the refinement changed the image
+    assert "6 spp after" in r.stdout
