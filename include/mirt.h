@@ -70,6 +70,15 @@ typedef struct mirt_scene {
     const int32_t  *node_right;
     int32_t         root;
     float           ambient[3];  /* LightSources::GetAmbientLight, LightSources.h:21       */
+    /* image textures (SimpleTexture2D_TGAImage, SimpleTexture2D.cpp:109-147); n_textures may be 0 and
+     * mat_texture NULL: every material then samples its single colour mat_albedo */
+    uint32_t        n_textures;
+    const uint32_t *tex_width;   /* [n]  m_width                                           */
+    const uint32_t *tex_height;  /* [n]  m_height                                          */
+    const uint32_t *tex_offset;  /* [n]  index of the texture's first texel in tex_rgba8/4 */
+    const uint8_t  *tex_rgba8;   /* m_pixelData of all textures back to back: R,G,B,A per texel, row 0 = top
+                                    (what tgaRead(.., TGA_READER_ABGR) returns, tga_reader.cpp) */
+    const int32_t  *mat_texture; /* [n_mats] texture sampled for the albedo (Lambertian, Metal), -1 = mat_albedo */
 } mirt_scene;
 
 /* The SimpleCamera members GetRay reads (SimpleCamera.h:35-56, SimpleCamera.cpp:55-60). */
@@ -209,6 +218,8 @@ int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32
  * tests bind it): op 0 x/y, 1 sqrt(x), 2 x^5 as Schlick evaluates it (Optics.h:31), 3 the [0,1)
  * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x. */
 int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
+/* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: uv = n (u,v) pairs -> n RGB triples of texture `tex` */
+int mirt_tex_sample_batch(mirt_ctx *ctx, uint32_t tex, const float *uv, size_t n, float *rgb_out);
 
 /* -- host utilities -------------------------------------------------------------------------- */
 /* PPMImageMaker::OutputRGBA8ToFile, PPMImageMaker.cpp:9-48 (ASCII P3, alpha dropped) */

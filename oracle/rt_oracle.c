@@ -412,7 +412,35 @@ static float schlick(float cosine, float ref_idx)
 /* ===================================================================================== */
 typedef struct { int alive; v3 atten; ray_t out; v3 emitted; } scat_t;
 
-static v3 mat_albedo(const orc_scene *sc, int m) { return V(sc->mat_albedo[3 * m], sc->mat_albedo[3 * m + 1], sc->mat_albedo[3 * m + 2]); }
+/* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: nearest texel, i = UINT32(u*W),
+ * j = UINT32((1-v)*H - 0.001f), clamped to the image (the `< 0` tests are dead for UINT32, :135-136);
+ * channel / 255.0f.  The float -> UINT32 conversion is MSVC x64's cvttss2si to 64 bits truncated to 32:
+ * values in (-1, 0) give 0, NaN and out-of-range give 0x8000000000000000 -> 0. */
+static uint32_t f2u32_msvc(float f)
+{
+    if (!(f > -9223372036854775808.0f && f < 9223372036854775808.0f)) return 0u;
+    return (uint32_t)(uint64_t)(int64_t)f;
+}
+static v3 tex_sample(const orc_scene *sc, uint32_t tex, float u, float v)
+{
+    uint32_t W = sc->tex_width[tex], H = sc->tex_height[tex];
+    uint32_t i = f2u32_msvc(u * (float)W);
+    uint32_t j = f2u32_msvc((1.0f - v) * (float)H - 0.001f);
+    if (i > W - 1) i = W - 1;
+    if (j > H - 1) j = H - 1;
+    const uint8_t *px = sc->tex_rgba8 + 4 * ((size_t)sc->tex_offset[tex] + (size_t)j * W + i);
+    return V((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+void orc_tex_sample_batch(const orc_scene *sc, uint32_t tex, const float *uv, size_t n, float *rgb_out)
+{
+    for (size_t k = 0; k < n; ++k) { v3 c = tex_sample(sc, tex, uv[2 * k], uv[2 * k + 1]); rgb_out[3 * k] = c.x; rgb_out[3 * k + 1] = c.y; rgb_out[3 * k + 2] = c.z; }
+}
+/* m_albedo->Sample(rec.m_u, rec.m_v), Materials.cpp:30,104 */
+static v3 mat_albedo(const orc_scene *sc, int m, float u, float v)
+{
+    if (sc->n_textures && sc->mat_texture && sc->mat_texture[m] >= 0) return tex_sample(sc, (uint32_t)sc->mat_texture[m], u, v);
+    return V(sc->mat_albedo[3 * m], sc->mat_albedo[3 * m + 1], sc->mat_albedo[3 * m + 2]);
+}
 
 static void scatter(const orc_scene *sc, const ray_t *r_in, const hit_t *rec, rng_t *g, scat_t *o)
 {
@@ -424,7 +452,7 @@ static void scatter(const orc_scene *sc, const ray_t *r_in, const hit_t *rec, rn
     case ORC_MAT_LAMBERTIAN: {                                             /* Materials.cpp:19-33 */
         v3 target = v_add(v_add(rec->pos, rec->nrm), rng_in_unit_sphere(g));
         o->out.org = rec->pos; o->out.dir = v_sub(target, rec->pos);
-        o->atten = mat_albedo(sc, m);                                      /* SimpleTexture2D.h:39 */
+        o->atten = mat_albedo(sc, m, rec->u, rec->v);                      /* SimpleTexture2D.h:39, SimpleTexture2D.cpp:130 */
         o->alive = v_dot(r_in->dir, rec->nrm) < 0;
         break;
     }
@@ -432,7 +460,7 @@ static void scatter(const orc_scene *sc, const ray_t *r_in, const hit_t *rec, rn
         v3 refl = reflect(v_normalize(r_in->dir), rec->nrm);
         o->out.org = rec->pos;
         o->out.dir = v_add(refl, v_scale(rng_in_unit_sphere(g), sc->mat_fuzz[m]));
-        o->atten = mat_albedo(sc, m);
+        o->atten = mat_albedo(sc, m, rec->u, rec->v);
         o->alive = v_dot(o->out.dir, rec->nrm) > 0;
         break;
     }

@@ -69,6 +69,11 @@ typedef struct orc_scene {
     const int32_t  *node_right;
     int32_t         root;        /* node index, or ~object when the scene is one object     */
     float           ambient[3];  /* LightSources::GetAmbientLight                           */
+    /* image textures (SimpleTexture2D_TGAImage); n_textures 0 / mat_texture NULL = single colours only */
+    uint32_t        n_textures;
+    const uint32_t *tex_width, *tex_height, *tex_offset;   /* [n] size and first texel index            */
+    const uint8_t  *tex_rgba8;   /* R,G,B,A per texel, row 0 = top                                     */
+    const int32_t  *mat_texture; /* [n_mats] texture index or -1                                       */
 } orc_scene;
 
 typedef struct orc_camera {      /* SimpleCamera members used by GetRay, 19 floats */
@@ -107,6 +112,9 @@ float    orc_map_minmax(uint32_t raw, float mn, float mx);    /* [min,max)  :9-1
 float    orc_map_minmax2(uint32_t raw, float mn, float mx);   /* [min,max]  :20-26 */
 /* exhaustive self-check of the division-free form of raw/4294967295.0 used on the device */
 uint64_t orc_check_div_u32max(uint32_t begin, uint32_t end);
+
+/* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147 */
+void orc_tex_sample_batch(const orc_scene *sc, uint32_t tex, const float *uv, size_t n, float *rgb_out);
 
 /* ---- primitive-level functions on raw arrays (test hooks) ---------------------------- */
 /* AABB.cpp:5-21 */

@@ -36,6 +36,8 @@ class SceneStruct(C.Structure):
         ("mat_ior", f32p), ("mat_emit", f32p),
         ("n_nodes", C.c_uint32), ("node_min", f32p), ("node_max", f32p), ("node_left", i32p),
         ("node_right", i32p), ("root", C.c_int32), ("ambient", C.c_float * 3),
+        ("n_textures", C.c_uint32), ("tex_width", u32p), ("tex_height", u32p), ("tex_offset", u32p),
+        ("tex_rgba8", u8p), ("mat_texture", i32p),
     ]
 
 
@@ -65,7 +67,7 @@ EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
     "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
-    "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_write_ppm", "mirt_write_image",
+    "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_tex_sample_batch", "mirt_write_ppm", "mirt_write_image",
 ]
 
 _lib = None
@@ -105,6 +107,7 @@ def load():
     lib.mirt_camera_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp]
     lib.mirt_philox_batch.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.mirt_arith_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, vp]
+    lib.mirt_tex_sample_batch.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp]
     lib.mirt_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
     lib.mirt_write_image.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
     for name in EXPORTS:
@@ -203,6 +206,12 @@ class Context:
                                               C.c_void_p(stream) if stream else None), "mirt_resolve_device")
 
     # ---- function-level entry points -------------------------------------------------------
+    def tex_sample_batch(self, tex, uv):
+        uv = _f32(uv, (-1, 2))
+        out = np.zeros((uv.shape[0], 3), np.float32)
+        self._ck(self.lib.mirt_tex_sample_batch(self.h, tex, _ptr(uv), uv.shape[0], _ptr(out)), "mirt_tex_sample_batch")
+        return out
+
     def aabb_hit_batch(self, bmin, bmax, org, dir_, t_min, t_max):
         bmin, bmax, org, dir_ = _f32(bmin, (-1, 3)), _f32(bmax, (-1, 3)), _f32(org, (-1, 3)), _f32(dir_, (-1, 3))
         out = np.zeros((org.shape[0], bmin.shape[0]), np.uint8)

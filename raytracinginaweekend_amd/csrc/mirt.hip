@@ -40,7 +40,7 @@ struct mirt_ctx {
     uint32_t lds_bytes = 0, lds_bytes2 = 0, lds_stack_bytes = 0;   // the stack comes last in the plan: the list walk launches without it
     bool prims_in_lds = false;
     mirt_camera cam{};
-    DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats;
+    DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -97,7 +97,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -178,6 +178,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     for (uint32_t m = 0; m < s->n_mats; ++m) {
         MatRec &r = mats[m]; memset(&r, 0, sizeof r);
         r.kind = s->mat_kind[m]; r.fuzz = s->mat_fuzz[m]; r.ior = s->mat_ior[m];
+        r.tex = (s->n_textures && s->mat_texture[m] >= 0) ? s->mat_texture[m] : -1;
         for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
     }
     if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
@@ -191,6 +192,19 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     HIPCHK(c, hipMemcpy(c->d_mats.p, mats.data(), mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
 
     SceneDev &d = c->sc;
+    d.texs = nullptr; d.texels = nullptr; d.n_textures = s->n_textures;
+    if (s->n_textures) {
+        std::vector<TexRec> texs(s->n_textures);
+        uint64_t n_texels = 0;
+        for (uint32_t t = 0; t < s->n_textures; ++t) {
+            texs[t] = TexRec{ s->tex_width[t], s->tex_height[t], s->tex_offset[t], 0u };
+            n_texels = std::max<uint64_t>(n_texels, (uint64_t)s->tex_offset[t] + (uint64_t)s->tex_width[t] * s->tex_height[t]);
+        }
+        if (c->d_texs.ensure(texs.size() * sizeof(TexRec)) || c->d_texels.ensure(n_texels * 4)) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
+        HIPCHK(c, hipMemcpy(c->d_texs.p, texs.data(), texs.size() * sizeof(TexRec), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_texels.p, s->tex_rgba8, n_texels * 4, hipMemcpyHostToDevice));   // R,G,B,A bytes = one little-endian word per texel
+        d.texs = (const TexRec *)c->d_texs.p; d.texels = (const uint32_t *)c->d_texels.p;
+    }
     d.prims = (const PrimRec *)c->d_prims.p; d.n_prims = s->n_prims;
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
@@ -294,24 +308,36 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
     return (uint32_t)n;
 }
 
+// k_trace<ACCEL, PLDS, TEX> for this scene and mode
+#define MIRT_TRACE_DISPATCH(mode, pl, tex, CALL)                                                                  \
+    do {                                                                                                          \
+        if (mode == 0) { if (pl) { if (tex) { CALL(0, true, true); } else { CALL(0, true, false); } } else { if (tex) { CALL(0, false, true); } else { CALL(0, false, false); } } }      \
+        else if (mode == 1) { if (pl) { if (tex) { CALL(1, true, true); } else { CALL(1, true, false); } } else { if (tex) { CALL(1, false, true); } else { CALL(1, false, false); } } } \
+        else { if (pl) { if (tex) { CALL(2, true, true); } else { CALL(2, true, false); } } else { if (tex) { CALL(2, false, true); } else { CALL(2, false, false); } } }                \
+    } while (0)
+
+static uint32_t trace_lds(const mirt_ctx *c, int mode)
+{
+    return mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
+}
 static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
-    const bool pl = c->prims_in_lds;
+    const uint32_t lds = trace_lds(c, mode);
+    const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     dim3 g(grid), b(MIRT_BLOCK);
-    if (mode == 0) { if (pl) hipLaunchKernelGGL((k_trace<0, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<0, false>), g, b, lds, st, a); }
-    else if (mode == 1) { if (pl) hipLaunchKernelGGL((k_trace<1, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<1, false>), g, b, lds, st, a); }
-    else { if (pl) hipLaunchKernelGGL((k_trace<2, true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace<2, false>), g, b, lds, st, a); }
+#define MIRT_CALL(A, P, T) hipLaunchKernelGGL((k_trace<A, P, T>), g, b, lds, st, a)
+    MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
+#undef MIRT_CALL
 }
 static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 {
-    const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
-    const bool pl = c->prims_in_lds;
+    const uint32_t lds = trace_lds(c, mode);
+    const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     int n = 0;
-    hipError_t e;
-    if (mode == 0) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<0, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<0, false>, MIRT_BLOCK, lds);
-    else if (mode == 1) e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<1, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<1, false>, MIRT_BLOCK, lds);
-    else e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<2, true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<2, false>, MIRT_BLOCK, lds);
+    hipError_t e = hipSuccess;
+#define MIRT_CALL(A, P, T) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<A, P, T>, MIRT_BLOCK, lds)
+    MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
+#undef MIRT_CALL
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 8; }
     return (uint32_t)n;
 }
@@ -414,6 +440,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     hipStream_t st = (hipStream_t)stream;
     const int mode = accel_mode(c, p->flags);
     if (c->engine == 1) return render_persistent(c, p, d_sum, st, stats, mode, spp_begin, spp_count, one_spp);
+    if (c->sc.n_textures) return fail(c, MIRT_ERR_STATE, "mirt_render_device: the wavefront engine (option engine=0) renders single-colour scenes only; this scene has image textures");
 
     // batch geometry: npix_b pixels x S samples <= capacity
     const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
@@ -722,6 +749,23 @@ extern "C" int mirt_philox_batch(mirt_ctx *c, const uint32_t *ctr, size_t n, con
     hipLaunchKernelGGL(k_philox_batch, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, dc, (uint32_t)n, key[0], key[1], dout);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpy(out, dout, 4 * n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return MIRT_OK;
+}
+
+extern "C" int mirt_tex_sample_batch(mirt_ctx *c, uint32_t tex, const float *uv, size_t n, float *rgb_out)
+{
+    if (!c || !uv || !rgb_out) return MIRT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MIRT_ERR_STATE, "mirt_tex_sample_batch: no scene");
+    if (tex >= c->sc.n_textures) return fail(c, MIRT_ERR_ARG, "mirt_tex_sample_batch: texture index out of range");
+    if (!n) return MIRT_OK;
+    CHECK_N(n);
+    HIPCHK(c, hipSetDevice(c->device));
+    Tmp t;
+    float *duv = t.up(uv, 2 * n), *dout = t.up<float>(nullptr, 3 * n);
+    NEED(duv && dout);
+    hipLaunchKernelGGL(k_tex_sample, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, c->sc, tex, duv, (uint32_t)n, dout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(rgb_out, dout, 3 * n * sizeof(float), hipMemcpyDeviceToHost));
     return MIRT_OK;
 }
 

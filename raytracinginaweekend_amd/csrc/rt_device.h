@@ -140,8 +140,10 @@ struct NodeRec {            // 32 B: one aligned 32-byte sector per (per-lane, d
 struct MatRec {             // 48 B
     uint32_t kind; float albedo[3];
     float    fuzz, ior, emit[3];
-    float    pad[3];
+    int32_t  tex;           // image texture sampled for the albedo, -1 = the single colour above
+    float    pad[2];
 };
+struct TexRec { uint32_t w, h, offset, pad; };   // offset: first texel in the RGBA8 texel array
 #define PI_KIND(i)   ((i) & 1u)
 #define PI_AAX(i)    (((i) >> 1) & 3u)
 #define PI_BAX(i)    (((i) >> 3) & 3u)
@@ -322,8 +324,33 @@ __device__ __forceinline__ uint32_t scatter_need(uint32_t kind, f3 dir_in, f3 nr
     return NEED_NONE;
 }
 
+// SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: nearest texel; float -> UINT32 as MSVC x64 does it
+// (cvttss2si to 64 bits, low half kept: (-1,0) -> 0, NaN / out of range -> 0), `> size-1` clamps, channel / 255.0f.
+__device__ __forceinline__ uint32_t f2u32_msvc(float f)
+{
+    if (!(f > -9223372036854775808.0f && f < 9223372036854775808.0f)) return 0u;
+    return (uint32_t)(unsigned long long)(long long)f;
+}
+__device__ __forceinline__ f3 tex_sample(const TexRec &t, const uint32_t *texels, float u, float v)
+{
+    uint32_t i = f2u32_msvc(u * (float)t.w);
+    uint32_t j = f2u32_msvc((1.0f - v) * (float)t.h - 0.001f);
+    if (i > t.w - 1u) i = t.w - 1u;
+    if (j > t.h - 1u) j = t.h - 1u;
+    const uint32_t px = texels[(size_t)t.offset + (size_t)j * t.w + i];
+    return mk((float)(px & 0xFFu) / 255.0f, (float)((px >> 8) & 0xFFu) / 255.0f, (float)((px >> 16) & 0xFFu) / 255.0f);
+}
+// m_albedo->Sample(rec.m_u, rec.m_v), Materials.cpp:30,104
 template <class M>
-__device__ __forceinline__ void scatter_finish(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
+__device__ __forceinline__ f3 albedo_of(const M &m, const TexRec *texs, const uint32_t *texels, float u, float v)
+{
+    if (m.tex >= 0) return tex_sample(texs[m.tex], texels, u, v);
+    return mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+}
+
+// albedo: what the material's texture returns at the hit (albedo_of, or the single colour when the scene has no images)
+template <class M>
+__device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
 {
     o.emitted = mk(0.0f, 0.0f, 0.0f);                                   // HomemadeRayTracer.cpp:173
     o.atten = mk(0.0f, 0.0f, 0.0f);
@@ -331,7 +358,7 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 dir_in, const f3 &
     uint32_t kind = m.kind;
     if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
         o.alive = dot(dir_in, nrm) < 0;
-        o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+        o.atten = albedo;
         f3 target = (pos + nrm) + sphere_pt;
         o.dir = target - pos;
     } else if (kind == MIRT_MAT_METAL || kind == MIRT_MAT_DIELECTRIC) {
@@ -339,7 +366,7 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 dir_in, const f3 &
         f3 refl = reflect(uv, nrm);                                     // Materials.cpp:102,209
         if (kind == MIRT_MAT_METAL) {                                   // Materials.cpp:99-106
             o.dir = refl + scale(sphere_pt, m.fuzz);
-            o.atten = mk(m.albedo[0], m.albedo[1], m.albedo[2]);
+            o.atten = albedo;
             o.alive = dot(o.dir, nrm) > 0;
         } else {                                                        // Materials.cpp:172-217
             float ior = m.ior;
@@ -362,13 +389,13 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 dir_in, const f3 &
 
 // one lane, draws in the reference's call order
 template <class M, class G>
-__device__ __forceinline__ void scatter(const M &m, f3 dir_in, const f3 &pos, const f3 &nrm, G &g, Scat &o)
+__device__ __forceinline__ void scatter(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, G &g, Scat &o)
 {
     uint32_t need = scatter_need(m.kind, dir_in, nrm, G::lazy);
     f3 sp = mk(0.0f, 0.0f, 0.0f); float u = 0.0f;
     if (need == NEED_SPHERE) sp = in_unit_sphere(g);
     else if (need == NEED_UNORM) u = scatter_unorm(g);
-    scatter_finish(m, dir_in, pos, nrm, sp, u, o);
+    scatter_finish(m, albedo, dir_in, pos, nrm, sp, u, o);
 }
 
 // ----------------------------------------------------------------------------- SimpleCamera.cpp:55-60

@@ -48,6 +48,8 @@ struct SceneDev {
     // short is what lets 8 workgroups share a CU.
     uint32_t stack_lds, spill_stride;
     int32_t *spill;
+    // image textures (SimpleTexture2D_TGAImage): per-texture size/offset and all texels as packed RGBA8 words
+    const TexRec *texs; const uint32_t *texels; uint32_t n_textures;
 };
 
 struct BounceArgs {
@@ -512,7 +514,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         if (active && !done) {
             Scat s;
             if (EXP_ON(4)) { s.alive = (lane & 7u) != 0u; s.dir = sp + h.nrm; s.atten = mk(0.5f, 0.5f, 0.5f); s.emitted = mk(0.0f, 0.0f, 0.0f); }
-            else scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
+            else scatter_finish(*M, mk(M->albedo[0], M->albedo[1], M->albedo[2]), d, h.pos, h.nrm, sp, un, s);   // engine 0 renders single-colour scenes only
             if (s.alive) { alive = true; no = h.pos; nd = s.dir; thr = thr * s.atten; }
             else { radiance = thr * s.emitted; done = true; }
         }
@@ -598,7 +600,8 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int ACCEL, bool PLDS>
+// TEX: the scene has image textures -- hits carry u,v (CalculateUV's atan2f/asinf for spheres) and the albedo is fetched
+template <int ACCEL, bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -723,7 +726,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
             } else {
                 const PrimRec *P = PLDS ? lv.prims : a.sc.prims;
-                prim_record(P[best], best, o, d, t_max, false, h);
+                prim_record(P[best], best, o, d, t_max, TEX, h);
                 if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
                     radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done = true;
                 } else if (!(depth < a.max_depth)) {                               // :173-174
@@ -740,7 +743,8 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
         // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         if (live && !done) {
             Scat s;
-            scatter_finish(*M, d, h.pos, h.nrm, sp, un, s);
+            const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
+            scatter_finish(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = thr * s.emitted; done = true; }
         }
@@ -857,13 +861,22 @@ __global__ void k_scatter_batch(SceneDev sc, const mirt_hit *hits, const float *
     f3 pos = mk(hh.pos[0], hh.pos[1], hh.pos[2]), nrm = mk(hh.nrm[0], hh.nrm[1], hh.nrm[2]);
     f3 din = mk(dir_in[3 * i], dir_in[3 * i + 1], dir_in[3 * i + 2]);
     Scat s; s.alive = false;
-    scatter(sc.mats[hh.mat], din, pos, nrm, g, s);
+    const MatRec &mr = sc.mats[hh.mat];
+    scatter(mr, albedo_of(mr, sc.texs, sc.texels, hh.u, hh.v), din, pos, nrm, g, s);
     alive[i] = s.alive ? 1 : 0;
     atten[3 * i] = s.atten.x; atten[3 * i + 1] = s.atten.y; atten[3 * i + 2] = s.atten.z;
     oorg[3 * i] = pos.x; oorg[3 * i + 1] = pos.y; oorg[3 * i + 2] = pos.z;
     odir[3 * i] = s.dir.x; odir[3 * i + 1] = s.dir.y; odir[3 * i + 2] = s.dir.z;
     oemit[3 * i] = s.emitted.x; oemit[3 * i + 1] = s.emitted.y; oemit[3 * i + 2] = s.emitted.z;
     if (consumed) consumed[i] = g.pos;
+}
+
+__global__ void k_tex_sample(SceneDev sc, uint32_t tex, const float *uv, uint32_t n, float *out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 c = tex_sample(sc.texs[tex], sc.texels, uv[2 * i], uv[2 * i + 1]);
+    out[3 * i] = c.x; out[3 * i + 1] = c.y; out[3 * i + 2] = c.z;
 }
 
 __global__ void k_camera_rays(mirt_camera cam, const float *uv, uint32_t n, const uint32_t *draws, uint32_t dpr,

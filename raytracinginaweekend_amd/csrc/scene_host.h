@@ -152,6 +152,14 @@ inline std::string validate(const mirt_scene &s)
         }
     }
     for (uint32_t m = 0; m < s.n_mats; ++m) if (s.mat_kind[m] > 3) return "bad material kind";
+    if (s.n_textures) {
+        if (!s.tex_width || !s.tex_height || !s.tex_offset || !s.tex_rgba8 || !s.mat_texture) return "null texture array";
+        for (uint32_t t = 0; t < s.n_textures; ++t) {
+            if (!s.tex_width[t] || !s.tex_height[t]) return "empty texture";
+            if ((uint64_t)s.tex_offset[t] + (uint64_t)s.tex_width[t] * s.tex_height[t] > 0xFFFFFFFFull) return "textures larger than 2^32 texels";
+        }
+        for (uint32_t m = 0; m < s.n_mats; ++m) if (s.mat_texture[m] >= (int32_t)s.n_textures) return "texture index out of range";
+    }
     if (s.n_nodes) {
         if (!s.node_min || !s.node_max || !s.node_left || !s.node_right) return "null BVH array";
         if (s.root < 0 || (uint32_t)s.root >= s.n_nodes) return "BVH root out of range";

@@ -5,6 +5,7 @@
 #include "../../include/mirt.h"
 
 class IMaterial;
+class ITexture2D;
 
 // The instance chain above a leaf hitable, outermost first.  The device record holds exactly
 // Translate o RotZ o RotY o RotX o leaf (each optional), the shape SimpleObjectRect/Cube/Sphere
@@ -23,7 +24,9 @@ class FlatScene
 public:
 	std::vector<uint32_t> prim_kind, prim_axes, prim_mat, obj_first, obj_count, mat_kind;
 	std::vector<float>    prim_off, prim_geom, prim_rot, mat_albedo, mat_fuzz, mat_ior, mat_emit, node_min, node_max;
-	std::vector<int32_t>  node_left, node_right;
+	std::vector<int32_t>  node_left, node_right, mat_texture;
+	std::vector<uint32_t> tex_width, tex_height, tex_offset;       // image textures (SimpleTexture2D_TGAImage)
+	std::vector<uint8_t>  tex_rgba8;
 	int32_t root = MIRT_CHILD_NONE;
 	float ambient[3] = { 0.0f, 0.0f, 0.0f };
 
@@ -39,5 +42,7 @@ public:
 
 private:
 	std::map<const IMaterial *, uint32_t> m_matIndex;
+	std::map<const ITexture2D *, int32_t> m_texIndex;
+	int32_t TextureIndex(const ITexture2D *t);                     // interns an image texture, returns its row
 	void PushCommon(const InstanceChain &c, uint32_t kind, uint32_t axes, const IMaterial *m);
 };

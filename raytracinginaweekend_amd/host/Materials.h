@@ -16,7 +16,7 @@ enum MaterialID
 
 class ITexture2D;
 
-struct FlatMaterial { uint32_t kind; float albedo[3]; float fuzz, ior; float emit[3]; };
+struct FlatMaterial { uint32_t kind; float albedo[3]; float fuzz, ior; float emit[3]; const ITexture2D *image; /* non-null: an image texture supplies the albedo */ };
 
 class IMaterial
 {

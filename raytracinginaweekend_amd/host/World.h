@@ -18,6 +18,9 @@ enum WorldID
 	// additions of this build (BASELINE.json configs 1 and the `#if 0` variant of reference World.cpp:83-89)
 	WORLD_ID_FOUR_SPHERES,
 	WORLD_ID_CORNELL_TWO_BOXES,
+	// the two image-textured materials the reference defines but no shipped world uses (Resouces.cpp:166-176):
+	// a soil-textured floor and back wall, a checker-plate metal ball, a white light, sky ambient
+	WORLD_ID_TEXTURED,
 };
 
 class World

@@ -88,8 +88,22 @@ uint32_t FlatScene::MaterialIndex(const IMaterial *m)
 	FlatMaterial f = m->Flatten();
 	uint32_t row = (uint32_t)mat_kind.size();
 	mat_kind.push_back(f.kind); mat_fuzz.push_back(f.fuzz); mat_ior.push_back(f.ior);
+	mat_texture.push_back(f.image ? TextureIndex(f.image) : -1);
 	for (int i = 0; i < 3; ++i) { mat_albedo.push_back(f.albedo[i]); mat_emit.push_back(f.emit[i]); }
 	m_matIndex[m] = row;
+	return row;
+}
+int32_t FlatScene::TextureIndex(const ITexture2D *t)
+{
+	auto it = m_texIndex.find(t);
+	if (it != m_texIndex.end()) return it->second;
+	const auto *img = dynamic_cast<const SimpleTexture2D_TGAImage *>(t);
+	if (!img) throw std::runtime_error("FlatScene: only single-colour and TGA image textures are representable");
+	if ((uint64_t)tex_rgba8.size() / 4 + (uint64_t)img->m_width * img->m_height > 0xFFFFFFFFull) throw std::runtime_error("FlatScene: textures larger than 2^32 texels");
+	int32_t row = (int32_t)tex_width.size();
+	tex_width.push_back(img->m_width); tex_height.push_back(img->m_height); tex_offset.push_back((uint32_t)(tex_rgba8.size() / 4));
+	tex_rgba8.insert(tex_rgba8.end(), img->m_pixelData.begin(), img->m_pixelData.end());
+	m_texIndex[t] = row;
 	return row;
 }
 void FlatScene::PushCommon(const InstanceChain &c, uint32_t kind, uint32_t axes, const IMaterial *m)
@@ -126,6 +140,8 @@ mirt_scene FlatScene::View() const
 	s.n_nodes = (uint32_t)node_left.size(); s.node_min = node_min.data(); s.node_max = node_max.data();
 	s.node_left = node_left.data(); s.node_right = node_right.data(); s.root = root;
 	for (int i = 0; i < 3; ++i) s.ambient[i] = ambient[i];
+	s.n_textures = (uint32_t)tex_width.size(); s.tex_width = tex_width.data(); s.tex_height = tex_height.data(); s.tex_offset = tex_offset.data();
+	s.tex_rgba8 = tex_rgba8.data(); s.mat_texture = mat_texture.data();
 	return s;
 }
 
@@ -228,19 +244,105 @@ void RotatedInstance::Flatten(FlatScene &out, const InstanceChain &chain) const
 }
 
 // =========================================================================================== Materials
-static void single_colour(const ITexture2D *t, float out[3])
+// the albedo texture of a material: a single colour goes into the material row, an image is referenced
+static void albedo_texture(const ITexture2D *t, FlatMaterial &f)
 {
 	if (!t) throw std::runtime_error("material without a texture");
-	if (!t->IsSingleColor()) throw std::runtime_error("image textures are not on the device path yet (SURVEY.md section 8f, rank 1)");
-	Vec3 c = t->Sample(0.0f, 0.0f);
-	out[0] = c.r(); out[1] = c.g(); out[2] = c.b();
+	if (t->IsSingleColor()) { Vec3 c = t->Sample(0.0f, 0.0f); f.albedo[0] = c.r(); f.albedo[1] = c.g(); f.albedo[2] = c.b(); }
+	else f.image = t;
 }
-FlatMaterial Lambertian::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_LAMBERTIAN; single_colour(m_albedo, f.albedo); return f; }
+FlatMaterial Lambertian::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_LAMBERTIAN; albedo_texture(m_albedo, f); return f; }
 Metal::Metal(ITexture2D *albedo, float fuzziness) : m_albedo(albedo)     // Materials.cpp:93-97
 {
 	m_fuzziness = (fuzziness < 1.0f) ? ((fuzziness >= 0.0f) ? fuzziness : 0.0f) : 1.0f;
 }
-FlatMaterial Metal::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_METAL; single_colour(m_albedo, f.albedo); f.fuzz = m_fuzziness; return f; }
+FlatMaterial Metal::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_METAL; albedo_texture(m_albedo, f); f.fuzz = m_fuzziness; return f; }
+
+// =========================================================================================== image textures
+void DecodeTGA(const std::vector<UINT8> &file, UINT32 &width, UINT32 &height, std::vector<UINT8> &rgba)
+{
+	auto bad = [](const char *why) { throw std::runtime_error(std::string("DecodeTGA: ") + why); };
+	if (file.size() < 18) bad("file shorter than the header");
+	const UINT32 idLength = file[0], type = file[2];
+	const UINT32 cmapOrigin = file[3] | (file[4] << 8), cmapLength = file[5] | (file[6] << 8), cmapDepth = file[7];
+	width = file[12] | (file[13] << 8); height = file[14] | (file[15] << 8);
+	const UINT32 depth = file[16], descriptor = file[17];
+	if (!width || !height) bad("empty image");
+	const bool rle = type == 9 || type == 10 || type == 11;
+	const UINT32 base = rle ? type - 8 : type;
+	if (base < 1 || base > 3) bad("unsupported image type");
+	if (base == 1 && (depth != 8 || (cmapDepth != 24 && cmapDepth != 32))) bad("colour-mapped images need 8-bit indices and a 24/32-bit palette");
+	if (base == 2 && depth != 24 && depth != 32) bad("true-colour images must be 24 or 32 bits");
+	if (base == 3 && depth != 8) bad("grey images must be 8 bits");
+	const size_t palette = 18 + (size_t)idLength;
+	size_t at = palette + (size_t)(cmapDepth / 8) * cmapLength;
+	const UINT32 bpp = depth / 8;
+	const size_t count = (size_t)width * height;
+	std::vector<UINT8> raw(count * bpp);
+	if (!rle) {
+		if (at + raw.size() > file.size()) bad("truncated pixel data");
+		memcpy(raw.data(), file.data() + at, raw.size());
+	} else {
+		size_t done = 0;
+		while (done < count) {
+			if (at >= file.size()) bad("truncated RLE stream");
+			const UINT32 packet = file[at++], n = (packet & 0x7F) + 1;
+			if (done + n > count) bad("RLE packet runs past the image");
+			if (packet & 0x80) {
+				if (at + bpp > file.size()) bad("truncated RLE stream");
+				for (UINT32 k = 0; k < n; ++k) memcpy(raw.data() + (done + k) * bpp, file.data() + at, bpp);
+				at += bpp;
+			} else {
+				if (at + (size_t)n * bpp > file.size()) bad("truncated RLE stream");
+				memcpy(raw.data() + done * bpp, file.data() + at, (size_t)n * bpp);
+				at += (size_t)n * bpp;
+			}
+			done += n;
+		}
+	}
+	rgba.assign(count * 4, 255);
+	const bool right = descriptor & 0x10, upper = descriptor & 0x20;
+	for (UINT32 i = 0; i < height; ++i)
+		for (UINT32 j = 0; j < width; ++j) {
+			const UINT8 *px = raw.data() + ((size_t)i * width + j) * bpp;
+			UINT8 r, g, b, a = 255;
+			if (base == 2) { b = px[0]; g = px[1]; r = px[2]; if (bpp == 4) a = px[3]; }
+			else if (base == 3) { r = g = b = px[0]; }
+			else {
+				const int idx = (int)px[0] - (int)cmapOrigin;
+				if (idx < 0 || (UINT32)idx >= cmapLength) { r = g = b = a = 255; }
+				else {
+					const size_t e = palette + (size_t)idx * (cmapDepth / 8);
+					if (e + cmapDepth / 8 > file.size()) bad("truncated palette");
+					b = file[e]; g = file[e + 1]; r = file[e + 2]; if (cmapDepth == 32) a = file[e + 3];
+				}
+			}
+			const UINT32 y = upper ? i : height - 1 - i, x = right ? width - 1 - j : j;
+			UINT8 *o = rgba.data() + ((size_t)y * width + x) * 4;
+			o[0] = r; o[1] = g; o[2] = b; o[3] = a;
+		}
+}
+SimpleTexture2D_TGAImage::SimpleTexture2D_TGAImage(const char *filePath)
+{
+	std::ifstream f(filePath, std::ios::binary);
+	if (!f) throw std::runtime_error(std::string("SimpleTexture2D_TGAImage: cannot open ") + filePath);
+	std::vector<UINT8> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	DecodeTGA(file, m_width, m_height, m_pixelData);
+}
+SimpleTexture2D_TGAImage::SimpleTexture2D_TGAImage(UINT32 width, UINT32 height, const UINT8 *rgba)
+{
+	if (!width || !height || !rgba) throw std::invalid_argument("SimpleTexture2D_TGAImage: empty image");
+	m_width = width; m_height = height; m_pixelData.assign(rgba, rgba + (size_t)width * height * 4);
+}
+Vec3 SimpleTexture2D_TGAImage::Sample(float u, float v) const             // SimpleTexture2D.cpp:130-147 (the render path samples on the device)
+{
+	auto toU32 = [](float f) -> UINT32 { if (!(f > -9223372036854775808.0f && f < 9223372036854775808.0f)) return 0u; return (UINT32)(UINT64)(long long)f; };
+	UINT32 i = toU32(u * m_width), j = toU32((1.0f - v) * m_height - 0.001f);
+	if (i > m_width - 1) i = m_width - 1;
+	if (j > m_height - 1) j = m_height - 1;
+	const UINT8 *px = m_pixelData.data() + ((size_t)j * m_width + i) * 4;
+	return Vec3(px[0] / 255.0f, px[1] / 255.0f, px[2] / 255.0f);
+}
 FlatMaterial Dielectric::Flatten() const { FlatMaterial f{}; f.kind = MIRT_MAT_DIELECTRIC; f.ior = m_refractiveIndex; return f; }
 FlatMaterial DiffuseLight::Flatten() const
 {
@@ -369,10 +471,21 @@ void Resources::LoadMaterials()                                          // Reso
 	m_materials.push_back(new Lambertian(colour(0.12f, 0.45f, 0.15f)));   // 4
 	m_materials.push_back(new Metal(colour(0.7f, 0.6f, 0.5f), 0.0f));     // MATERIAL_ID_METAL
 	m_materials.push_back(new Dielectric(1.5f));                          // MATERIAL_ID_DIELECTRIC
-	// the two TGA-textured materials (Resouces.cpp:166-176) are unused by both worlds; until image
-	// textures are on the device path their slots hold mid-grey stand-ins so the later ids keep their values
-	m_materials.push_back(new Lambertian(colour(0.5f, 0.5f, 0.5f)));      // MATERIAL_ID_IMAGE_BASED_GROUND_SOIL
-	m_materials.push_back(new Metal(colour(0.5f, 0.5f, 0.5f), 0.7f));     // MATERIAL_ID_IMAGE_BASED_METAL_CHECKER
+	// the two TGA-textured materials (Resouces.cpp:166-176; unused by the shipped worlds).  The reference reads
+	// ..\\Assets\\*.tga relative to its working directory; here the directory comes from $MIRT_ASSETS (default
+	// ../Assets), and a file that is not there (one of the two is missing from the reference repository itself)
+	// leaves a mid-grey stand-in so the later ids keep their values
+	auto image = [&](const char *name) -> ITexture2D * {
+		const char *dir = getenv("MIRT_ASSETS");
+		std::string path = std::string(dir ? dir : "../Assets") + "/" + name;
+		struct stat st;
+		if (stat(path.c_str(), &st) != 0) return colour(0.5f, 0.5f, 0.5f);
+		ITexture2D *t = new SimpleTexture2D_TGAImage(path.c_str());
+		m_textures.push_back(t);
+		return t;
+	};
+	m_materials.push_back(new Lambertian(image("pab_ground_soil_001_c.tga")));          // MATERIAL_ID_IMAGE_BASED_GROUND_SOIL
+	m_materials.push_back(new Metal(image("pro_metal_checker_plate_001_c.tga"), 0.7f)); // MATERIAL_ID_IMAGE_BASED_METAL_CHECKER
 	m_materials.push_back(new DiffuseLight(Vec3(4.0f, 4.0f, 4.0f)));      // WHITE
 	m_materials.push_back(new DiffuseLight(Vec3(15.0f, 15.0f, 15.0f)));   // BRIGHT
 	m_materials.push_back(new DiffuseLight(Vec3(4.0f, 0.0f, 0.0f)));      // RED
@@ -441,6 +554,13 @@ void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // Worl
 			camera->Initialize(Vec3(0.0f, 0.64f, 4.63f), Vec3(0.0f, -0.26f, -1.0f), 30.0f, 1.0f, 10000.0f, 0.0f, 10.0f, 1.0f);
 		}
 		m_lightSources = new LightSources(this, objects, Vec3(0.0f, 0.0f, 0.0f));
+	} else if (wid == WORLD_ID_TEXTURED) {
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 0.0f, 0.0f), none, 4.0f, 4.0f, FALSE, nullptr, mat(MATERIAL_ID_IMAGE_BASED_GROUND_SOIL), this));
+		objects.push_back(new SimpleObjectRect(XY_RECT, Vec3(0.0f, 1.5f, -2.0f), none, 4.0f, 3.0f, FALSE, nullptr, mat(MATERIAL_ID_IMAGE_BASED_GROUND_SOIL), this));
+		objects.push_back(new SimpleObjectSphere(Vec3(0.0f, 0.7f, 0.0f), 0.7f, nullptr, mat(MATERIAL_ID_IMAGE_BASED_METAL_CHECKER), this));
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 3.0f, 0.0f), none, 1.5f, 1.5f, TRUE, nullptr, mat(MATERIAL_ID_LIGHTSOURCE_WHITE), this));
+		camera->Initialize(Vec3(0.0f, 1.5f, 5.0f), Vec3(0.0f, 0.7f, 0.0f), 35.0f, 1.0f, 10000.0f, 0.0f, 10.0f, 1.0f);
+		m_lightSources = new LightSources(this, objects, Vec3(0.5f, 0.6f, 0.8f));
 	} else {
 		throw std::invalid_argument("World::ConstructWorld: unknown world id");
 	}
@@ -755,6 +875,17 @@ int mirt_host_camera_script(int world_id, float aspect, uint64_t scene_seed, con
 			camera.Export(out_per_frame[f]);
 		}
 		world.DeconstructWorld();
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// DecodeTGA through the C shim: returns 0 and the size; rgba (capacity cap bytes) receives R,G,B,A, row 0 = top
+int mirt_host_decode_tga(const char *path, uint32_t *w, uint32_t *h, uint8_t *rgba, size_t cap, char *err, size_t errlen)
+{
+	try {
+		SimpleTexture2D_TGAImage img(path);
+		*w = img.m_width; *h = img.m_height;
+		if (img.m_pixelData.size() > cap) throw std::runtime_error("output buffer too small");
+		memcpy(rgba, img.m_pixelData.data(), img.m_pixelData.size());
 		return 0;
 	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
 }

@@ -24,24 +24,33 @@ class FlatScene:
     def __init__(self, ambient=(0.0, 0.0, 0.0)):
         self.kind, self.off, self.geom, self.axes, self.rot, self.pmat = [], [], [], [], [], []
         self.obj_first, self.obj_count = [], []
-        self.mkind, self.albedo, self.fuzz, self.ior, self.emit = [], [], [], [], []
+        self.mkind, self.albedo, self.fuzz, self.ior, self.emit, self.mtex = [], [], [], [], [], []
+        self.textures = []    # (h, w, 4) uint8 arrays, row 0 = top (SimpleTexture2D_TGAImage::m_pixelData)
         self.ambient = tuple(float(x) for x in ambient)
         self.nodes = None     # optional (node_min, node_max, left, right, root)
         self._arrays = None
 
     # ---- materials (Materials.cpp) ---------------------------------------------------------
-    def _mat(self, kind, albedo=(0, 0, 0), fuzz=0.0, ior=0.0, emit=(0, 0, 0)):
+    def _mat(self, kind, albedo=(0, 0, 0), fuzz=0.0, ior=0.0, emit=(0, 0, 0), texture=-1):
         self.mkind.append(kind); self.albedo.append(albedo); self.fuzz.append(fuzz); self.ior.append(ior); self.emit.append(emit)
+        self.mtex.append(int(texture))
         self._arrays = None
         return len(self.mkind) - 1
 
-    def lambertian(self, albedo):
-        return self._mat(capi.MAT_LAMBERTIAN, albedo=albedo)
+    def texture(self, rgba8):
+        """SimpleTexture2D_TGAImage (SimpleTexture2D.cpp:109-118) from decoded texels, (h, w, 4) uint8, row 0 = top."""
+        t = np.ascontiguousarray(rgba8, np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self.textures.append(t); self._arrays = None
+        return len(self.textures) - 1
 
-    def metal(self, albedo, fuzziness):
+    def lambertian(self, albedo=(0.5, 0.5, 0.5), texture=-1):
+        return self._mat(capi.MAT_LAMBERTIAN, albedo=albedo, texture=texture)
+
+    def metal(self, albedo, fuzziness, texture=-1):
         f = F(fuzziness)
         f = (f if f >= 0 else F(0)) if f < 1 else F(1)          # Materials.cpp:96
-        return self._mat(capi.MAT_METAL, albedo=albedo, fuzz=float(f))
+        return self._mat(capi.MAT_METAL, albedo=albedo, fuzz=float(f), texture=texture)
 
     def dielectric(self, ior):
         return self._mat(capi.MAT_DIELECTRIC, ior=ior)
@@ -99,6 +108,12 @@ class FlatScene:
                 prim_rot=f32(self.rot, 6), prim_mat=u32(self.pmat), obj_first=u32(self.obj_first), obj_count=u32(self.obj_count),
                 mat_kind=u32(self.mkind), mat_albedo=f32(self.albedo, 3), mat_fuzz=f32(self.fuzz, 1), mat_ior=f32(self.ior, 1),
                 mat_emit=f32(self.emit, 3))
+            if self.textures:
+                sizes = np.array([t.shape[0] * t.shape[1] for t in self.textures], np.uint64)
+                self._arrays.update(tex_width=u32([t.shape[1] for t in self.textures]), tex_height=u32([t.shape[0] for t in self.textures]),
+                                    tex_offset=u32(np.concatenate([[0], np.cumsum(sizes)[:-1]])),
+                                    tex_rgba8=np.concatenate([t.reshape(-1) for t in self.textures]),
+                                    mat_texture=np.ascontiguousarray(self.mtex + [-1] * (len(self.mkind) - len(self.mtex)), np.int32))
         return self._arrays
 
     @property
@@ -116,7 +131,7 @@ class FlatScene:
         s = capi.SceneStruct()
         s.n_prims = len(self.kind); s.n_objects = len(self.obj_first); s.n_mats = len(self.mkind)
         for k, v in a.items():
-            ct = {np.dtype(np.uint32): capi.u32p, np.dtype(np.float32): capi.f32p}[v.dtype]
+            ct = {np.dtype(np.uint32): capi.u32p, np.dtype(np.float32): capi.f32p, np.dtype(np.uint8): capi.u8p, np.dtype(np.int32): capi.i32p}[v.dtype]
             setattr(s, k, v.ctypes.data_as(ct))
         if self.nodes is not None:
             mn, mx, l, r, root = self.nodes
@@ -125,6 +140,7 @@ class FlatScene:
         else:
             s.n_nodes = 0; s.root = capi.CHILD_NONE
         s.ambient = (C.c_float * 3)(*self.ambient)
+        s.n_textures = len(self.textures)
         return s
 
 
@@ -203,6 +219,21 @@ def cornell_two_boxes(aspect=1.0):
     h = F(0.6)
     s.cube((0.32, float(F(-1.0) + h * F(0.5)), 0.4), (0.0, -0.3, 0.0), (float(h),) * 3, lam3)
     cam = make_camera((0.0, 0.0, 4.0), (0.0, 0.0, 0.0), 40.0, 0.0, aspect)
+    return s, cam
+
+
+def textured_world(aspect, soil_rgba, checker_rgba):
+    """WORLD_ID_TEXTURED of the host layer: the two image-textured materials of Resouces.cpp:166-176 on a floor,
+    a back wall and a ball.  soil_rgba / checker_rgba: decoded texels, (h, w, 4) uint8, row 0 = top."""
+    s = FlatScene(ambient=(0.5, 0.6, 0.8))
+    soil = s.lambertian(texture=s.texture(soil_rgba))                   # Lambertian(texture)
+    checker = s.metal((0.5, 0.5, 0.5), 0.7, texture=s.texture(checker_rgba))   # Metal(texture, 0.7f)
+    white = s.diffuse_light((4.0, 4.0, 4.0))                            # MATERIAL_ID_LIGHTSOURCE_WHITE
+    s.rect(XZ_RECT, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 4.0, 4.0, False, soil)
+    s.rect(XY_RECT, (0.0, 1.5, -2.0), (0.0, 0.0, 0.0), 4.0, 3.0, False, soil)
+    s.sphere((0.0, 0.7, 0.0), 0.7, checker)
+    s.rect(XZ_RECT, (0.0, 3.0, 0.0), (0.0, 0.0, 0.0), 1.5, 1.5, True, white)
+    cam = make_camera((0.0, 1.5, 5.0), (0.0, 0.7, 0.0), 35.0, 0.0, aspect)
     return s, cam
 
 

@@ -33,7 +33,34 @@ def attach_tree(s, seed):
     return draws
 
 
+def make_f7():
+    """F7: image textures -- texel fetches (edge cases included), textured Scatter with explicit draws, a small image."""
+    soil, checker = H.synthetic_texture(37, 23, 1, "ramp"), H.synthetic_texture(64, 48, 2, "checker")
+    s, cam = scene.textured_world(1.5, soil, checker)
+    rng = np.random.default_rng(17)
+    uv = rng.uniform(-0.05, 1.05, (4096, 2)).astype(np.float32)
+    uv[:14] = np.array([[0, 0], [1, 1], [0, 1], [1, 0], [0.999999, 1e-7], [-0.25, 0.5], [1.5, -0.5], [0.5, 2.0], [-3.0, 0.5],
+                        [np.nan, 0.5], [0.5, np.nan], [np.inf, 0.5], [0.5, -np.inf], [1e30, 1e-30]], np.float32)
+    f7 = dict(soil=soil, checker=checker, uv=uv, sample0=orc.tex_sample_batch(s, 0, uv), sample1=orc.tex_sample_batch(s, 1, uv))
+    n = 2048
+    hits = np.zeros(n, capi.HIT_DTYPE)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    hits["nrm"] = nrm.astype(np.float32); hits["pos"] = rng.uniform(-1, 1, (n, 3)).astype(np.float32); hits["t"] = 1.0
+    hits["mat"] = np.arange(n) % len(s.mkind); hits["u"] = uv[:n, 0]; hits["v"] = uv[:n, 1]
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    draws = rng.integers(0, 2 ** 32, (n, 3 * 64), dtype=np.uint64).astype(np.uint32)
+    o = orc.scatter_batch(s, hits, d, draws)
+    keep = int(o["consumed"].max())
+    f7.update(hits=hits, dir_in=d, draws=draws[:, :keep], **{"out_" + k: v for k, v in o.items()})
+    f7["image_sum"], _ = orc.trace(s, cam, 60, 40, 4, 50, 3, orc.FLAG_ACCEL_LIST)
+    np.savez_compressed(os.path.join(OUT, "f7_textures.npz"), **f7)
+
+
 def main():
+    if sys.argv[1:] == ["f7"]:
+        make_f7()
+        return
+    make_f7()
     # F1: per-primitive hits + AABB
     f1 = {}
     for wn in ("cornell", "two_boxes", "spheres4"):

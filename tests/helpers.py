@@ -58,3 +58,79 @@ def assert_hits_equal(g, o, what="", uv_tol=None):
 def psnr(a, b, peak=1.0):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
     return float("inf") if mse == 0 else 10.0 * np.log10(peak * peak / mse)
+
+
+# ---- image textures ------------------------------------------------------------------------------------------
+def synthetic_texture(w, h, seed, kind="checker"):
+    """A deterministic RGBA8 image, (h, w, 4), row 0 = top: a noisy checker board or a colour ramp."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    if kind == "checker":
+        base = np.where(((xx // max(1, w // 8)) + (yy // max(1, h // 8))) % 2 == 0, 200, 60)[..., None] + rng.integers(-40, 40, (h, w, 3))
+    else:
+        base = np.stack([xx * 255 // max(1, w - 1), yy * 255 // max(1, h - 1), (xx + yy) * 255 // max(1, w + h - 2)], axis=-1) + rng.integers(-8, 8, (h, w, 3))
+    img = np.empty((h, w, 4), np.uint8)
+    img[..., :3] = np.clip(base, 0, 255).astype(np.uint8)
+    img[..., 3] = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    return img
+
+
+def write_tga(path, rgba, kind="rgb24", rle=False, origin="ll", id_bytes=b""):
+    """Writes `rgba` ((h, w, 4) uint8, row 0 = top) as a TGA file: kind rgb24 | rgb32 | gray | cmap24 | cmap32,
+    optionally run-length encoded, with the first stored pixel at the given corner (ll, ul, lr, ur).
+    Returns the RGBA image a decoder must produce (alpha 255 unless the file stores it; grey replicates)."""
+    h, w = rgba.shape[:2]
+    exp = rgba.copy()
+    stored = rgba[::-1] if origin[0] == "l" else rgba
+    stored = stored[:, ::-1] if origin[1] == "r" else stored
+    desc = (0x20 if origin[0] == "u" else 0) | (0x10 if origin[1] == "r" else 0)
+    palette = b""
+    cmap_len = cmap_depth = 0
+    if kind in ("rgb24", "rgb32"):
+        bpp = 3 if kind == "rgb24" else 4
+        px = stored[..., [2, 1, 0, 3]][..., :bpp].reshape(-1, bpp)                # B,G,R(,A)
+        itype = 2
+        if bpp == 3:
+            exp[..., 3] = 255
+    elif kind == "gray":
+        bpp, itype = 1, 3
+        px = stored[..., :1].reshape(-1, 1)
+        exp[..., 1] = exp[..., 0]; exp[..., 2] = exp[..., 0]; exp[..., 3] = 255
+    else:
+        bpp, itype = 1, 1
+        cbytes = 3 if kind == "cmap24" else 4
+        q = (stored[..., :3] // 64).astype(np.uint32)                                 # 64-entry palette from quantised colour
+        idx = (q[..., 0] * 16 + q[..., 1] * 4 + q[..., 2]).astype(np.uint8)
+        pal = np.array([[(i // 16) * 64 + 17, ((i // 4) % 4) * 64 + 29, (i % 4) * 64 + 5, 100 + i] for i in range(64)], np.uint8)   # R,G,B,A
+        palette = pal[:, [2, 1, 0, 3]][:, :cbytes].tobytes()
+        cmap_len, cmap_depth = 64, cbytes * 8
+        px = idx.reshape(-1, 1)
+        full = pal[idx]
+        full = full[:, ::-1] if origin[1] == "r" else full
+        full = full[::-1] if origin[0] == "l" else full
+        exp = full.copy()
+        if cbytes == 3:
+            exp[..., 3] = 255
+    px = np.ascontiguousarray(px, np.uint8)
+    if rle:
+        out = bytearray()
+        i, n = 0, px.shape[0]
+        while i < n:
+            run = 1
+            while i + run < n and run < 128 and np.array_equal(px[i + run], px[i]):
+                run += 1
+            if run > 1:
+                out.append(0x80 | (run - 1)); out += px[i].tobytes(); i += run
+            else:
+                j = i + 1
+                while j < n and j - i < 128 and not (j + 1 < n and np.array_equal(px[j], px[j + 1])):
+                    j += 1
+                out.append(j - i - 1); out += px[i:j].tobytes(); i = j
+        data = bytes(out); itype += 8
+    else:
+        data = px.tobytes()
+    head = bytes([len(id_bytes), 1 if palette else 0, itype, 0, 0, cmap_len & 255, cmap_len >> 8, cmap_depth, 0, 0, 0, 0,
+                  w & 255, w >> 8, h & 255, h >> 8, bpp * 8, desc | (8 if kind == "rgb32" else 0)])
+    with open(path, "wb") as f:
+        f.write(head + id_bytes + palette + data)
+    return exp

@@ -47,6 +47,14 @@ def build_world(world_id, aspect, seed):
         fs.obj_first = _arr(s.obj_first, no).tolist(); fs.obj_count = _arr(s.obj_count, no).tolist()
         fs.mkind = _arr(s.mat_kind, nm).tolist(); fs.albedo = _arr(s.mat_albedo, nm, 3); fs.fuzz = _arr(s.mat_fuzz, nm)
         fs.ior = _arr(s.mat_ior, nm); fs.emit = _arr(s.mat_emit, nm, 3)
+        if s.n_textures:
+            tw, th, to = _arr(s.tex_width, s.n_textures), _arr(s.tex_height, s.n_textures), _arr(s.tex_offset, s.n_textures)
+            total = int(to[-1]) + int(tw[-1]) * int(th[-1])
+            texels = np.ctypeslib.as_array(s.tex_rgba8, shape=(total * 4,)).copy()
+            fs.textures = [texels[4 * int(o): 4 * (int(o) + int(w_) * int(h_))].reshape(int(h_), int(w_), 4) for w_, h_, o in zip(tw, th, to)]
+            fs.mtex = _arr(s.mat_texture, nm).tolist()
+        else:
+            fs.mtex = [-1] * nm
         fs.set_bvh(_arr(s.node_min, nn, 3), _arr(s.node_max, nn, 3), _arr(s.node_left, nn), _arr(s.node_right, nn), s.root)
         cam = capi.CameraStruct.from_buffer_copy(bytes(lib().mirt_host_world_camera(h).contents))
         return fs, cam
@@ -64,6 +72,19 @@ def render(world_id, w, h, spp, depth=50, scene_seed=1, seed=0x5EED, one_spp=Fal
     return out
 
 
+def decode_tga(path, cap=1 << 24):
+    L = lib()
+    L.mirt_host_decode_tga.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.mirt_host_decode_tga.restype = C.c_int
+    w, h = C.c_uint32(), C.c_uint32()
+    buf = np.zeros(cap, np.uint8)
+    err = C.create_string_buffer(512)
+    if L.mirt_host_decode_tga(os.fsencode(path), C.byref(w), C.byref(h), buf.ctypes.data_as(C.c_void_p), cap, err, 512) != 0:
+        raise RuntimeError(err.value.decode())
+    return buf[: w.value * h.value * 4].reshape(h.value, w.value, 4).copy()
+
+
+WORLD_TEXTURED = 4
 KEY = {"W": ord("W"), "A": ord("A"), "S": ord("S"), "D": ord("D"), "L": 0x25, "U": 0x26, "R": 0x27, "P": 0x28}
 
 

@@ -47,6 +47,7 @@ def lib():
         L.orc_world_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, vp, vp]; L.orc_world_hit_batch.restype = None
         L.orc_scatter_batch.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp, vp, vp, vp]; L.orc_scatter_batch.restype = None
         L.orc_camera_rays.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp]; L.orc_camera_rays.restype = None
+        L.orc_tex_sample_batch.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp]; L.orc_tex_sample_batch.restype = None
         L.orc_camera_init.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float]; L.orc_camera_init.restype = None
         L.orc_object_bounds.argtypes = [vp, vp, vp]; L.orc_object_bounds.restype = None
         L.orc_bvh_build_reference.argtypes = [vp, vp, C.c_size_t, vp, vp, vp, vp, vp]; L.orc_bvh_build_reference.restype = C.c_int32
@@ -139,6 +140,14 @@ def scatter_batch(scene, hits, dir_in, draws):
     dr = np.zeros((n, 3), np.float32); em = np.zeros((n, 3), np.float32); used = np.zeros(n, np.uint32)
     lib().orc_scatter_batch(C.byref(st), _p(hits), _p(dir_in), n, _p(draws), draws.shape[1], _p(alive), _p(att), _p(org), _p(dr), _p(em), _p(used))
     return dict(alive=alive, atten=att, org=org, dir=dr, emit=em, consumed=used)
+
+
+def tex_sample_batch(scene, tex, uv):
+    st = scene.as_struct()
+    uv = _f32(uv, (-1, 2))
+    out = np.zeros((uv.shape[0], 3), np.float32)
+    lib().orc_tex_sample_batch(C.byref(st), tex, _p(uv), uv.shape[0], _p(out))
+    return out
 
 
 def camera_rays(cam, uv, draws):

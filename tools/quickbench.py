@@ -9,6 +9,9 @@ world = sys.argv[2] if len(sys.argv) > 2 else "cornell"
 w, h = (1024, 1024) if world == "cornell" else (1200, 800)
 if world == "cornell":
     s, cam = scene.cornell_box(1.0)
+elif world == "textured":                     # two 1024^2 image textures (4 MB each) on floor, wall and ball
+    from tests import helpers as H
+    s, cam = scene.textured_world(w / h, H.synthetic_texture(1024, 1024, 1, "ramp"), H.synthetic_texture(1024, 1024, 2, "checker"))
 elif world == "spheres1m":                    # BASELINE config 4: ~1M spheres, camera raised to see the field
     s, cam = scene.spheres_world(w / h, grid=500, look_from=(26.0, 6.0, 6.0))
 else:
