@@ -91,11 +91,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
     def step(stats=None):
         d_sum.zero_()
         ctx.render_device(params, d_sum.data_ptr(), stream, stats)
         if dist is not None:
+            if stats is not None:
+                ev[0].record()
             dist.reduce(d_sum, dst=0, op=dist.ReduceOp.SUM)
+            if stats is not None:
+                ev[1].record()
         if rank == 0:
             ctx.resolve_device(d_sum.data_ptr(), W, H, SPP, flags, None, d_rgba.data_ptr(), stream)
 
@@ -117,6 +123,7 @@ def main():
     st = capi.Stats()
     step(st)
     torch.cuda.synchronize(dev)
+    reduce_ms = float(ev[0].elapsed_time(ev[1])) if dist is not None else 0.0     # the one exchange of the path, rank 0's view
     ctx.set_option("time_launches", 0)
     rays_local = torch.tensor([float(st.rays), float(st.samples)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -175,7 +182,8 @@ def main():
             "mrays_per_s": round(msamples * rays_per_sample, 2), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": roofline, "roofline_other": other,
             "whole_render": {"device_ms_rank0": round(st.device_ms, 3), "dominant_kernel_ms": round(st.extend_ms, 3),
-                             "batches": int(st.batches), "launches": int(st.bounce_launches)},
+                             "batches": int(st.batches), "launches": int(st.bounce_launches),
+                             "rccl_reduce_ms": round(reduce_ms, 3), "reduce_bytes": int(W) * H * 3 * 4 if world > 1 else 0},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(sc, cam, W, H, args, ctx)
