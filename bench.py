@@ -141,7 +141,7 @@ def main():
         launches = max(1, int(st.extend_launches))
         k_s = st.extend_ms * 1e-3
         if args.engine == 1:
-            kname = "k_trace<0,true>"
+            kname = "k_trace<true,false>"
             k_rays = float(st.rays)
             k_flop = k_rays * FLOP_PER_RAY + float(st.samples) * FLOP_PER_SAMPLE_FIXED
             k_bytes = float(st.samples) * RAD_BYTES                       # the only per-path HBM traffic: one radiance slot

@@ -48,9 +48,10 @@ struct mirt_ctx {
     uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
     bool time_launches = false;
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
-    uint32_t lds_budget = 8u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
+    uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
-    uint32_t stack_lds = 8;                // traversal-stack levels kept in LDS (1 KiB each); likewise
+    uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
+    uint32_t stack_lds = 2;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
@@ -118,6 +119,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
     if (!strcmp(name, "lds_budget")) { if (value < 4096 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_budget out of range"); c->lds_budget = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "engine")) { if (value < 0 || value > 1) return fail(c, MIRT_ERR_ARG, "engine must be 0 (wavefront) or 1 (persistent)"); c->engine = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
@@ -220,8 +222,8 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.stack_lds = std::min<uint32_t>(d.stack_depth, c->stack_lds);
     d.spill = nullptr; d.spill_stride = 0;
     uint32_t used = d.stack_lds * MIRT_BLOCK * 4u;
-    d.lds_mats = (s->n_mats * sizeof(MatRec) <= 6u * 1024u) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
-    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 16u * 1024u;
+    d.lds_mats = (s->n_mats * sizeof(MatRec) <= c->lds_mats) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
+    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 4u * 1024u;       // scenes the list walk is meant for; larger ones keep the LDS for residency
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
     const uint32_t room_bytes = used < budget ? budget - used : 0u;
     c->sc2 = d;
@@ -308,7 +310,7 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
     return (uint32_t)n;
 }
 
-// k_trace<ACCEL, PLDS, TEX> for this scene and mode
+// k_trace<PLDS, TEX> (list) or k_trace_bvh<ACCEL, PLDS, TEX> for this scene and mode
 #define MIRT_TRACE_DISPATCH(mode, pl, tex, CALL)                                                                  \
     do {                                                                                                          \
         if (mode == 0) { if (pl) { if (tex) { CALL(0, true, true); } else { CALL(0, true, false); } } else { if (tex) { CALL(0, false, true); } else { CALL(0, false, false); } } }      \
@@ -325,7 +327,7 @@ static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32
     const uint32_t lds = trace_lds(c, mode);
     const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     dim3 g(grid), b(MIRT_BLOCK);
-#define MIRT_CALL(A, P, T) hipLaunchKernelGGL((k_trace<A, P, T>), g, b, lds, st, a)
+#define MIRT_CALL(A, P, T) do { if (A == 0) hipLaunchKernelGGL((k_trace<P, T>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace_bvh<(A == 0 ? 1 : A), P, T>), g, b, lds, st, a); } while (0)
     MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
 #undef MIRT_CALL
 }
@@ -335,7 +337,7 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
     const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     int n = 0;
     hipError_t e = hipSuccess;
-#define MIRT_CALL(A, P, T) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<A, P, T>, MIRT_BLOCK, lds)
+#define MIRT_CALL(A, P, T) do { if (A == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<P, T>, MIRT_BLOCK, lds); else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_bvh<(A == 0 ? 1 : A), P, T>, MIRT_BLOCK, lds); } while (0)
     MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
 #undef MIRT_CALL
     if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 8; }

@@ -602,7 +602,7 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // TEX: the scene has image textures -- hits carry u,v (CalculateUV's atan2f/asinf for spheres) and the albedo is fetched
 template <int ACCEL, bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
+__device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
@@ -759,6 +759,13 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a)
     __syncthreads();
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
 }
+
+// The list walk is VALU-bound and lives with 7 waves per SIMD; the BVH walks wait on node fetches, so they are
+// compiled for 8 waves per SIMD (<= 64 VGPRs; a three-dword spill) and launched with a small LDS plan.
+template <bool PLDS, bool TEX>
+__global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
+template <int ACCEL, bool PLDS, bool TEX>
+__global__ void __launch_bounds__(MIRT_BLOCK, 8) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
