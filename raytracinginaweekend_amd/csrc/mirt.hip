@@ -1,4 +1,4 @@
-// mirt.hip -- C ABI of libmirt.so (include/mirt.h): context, scene upload, the wavefront render
+// mirt.hip -- C ABI of libmirt.so (include/mirt.h): context, scene upload, the render
 // loop that drives the gfx950 kernels of rt_kernels.h, and the function-level parity entry points.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see build.py).
 #include <hip/hip_runtime.h>
@@ -481,12 +481,6 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     if (bind_spill(c, a.sc, grid_max)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed"); a.rad = (float4 *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
-#ifdef MIRT_STAMPS
-    static unsigned long long *d_stamps = nullptr;
-    if (!d_stamps) HIPCHK(c, hipMalloc(&d_stamps, 16 * sizeof(unsigned long long)));
-    HIPCHK(c, hipMemsetAsync(d_stamps, 0, 16 * sizeof(unsigned long long), st));
-    a.stamps = d_stamps;
-#endif
     a.chunk_shift = chunk_shift; a.cap_slots = (uint32_t)cap_slots; a.overflow = overflow;
     uint32_t launches = 0, batch = 0;
     const bool timed = stats && c->time_launches;
@@ -535,16 +529,6 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
             stats->depth_ms[ev_first[i]] += t;
             if (ev_first[i] == 0) { stats->first_ms += t; stats->first_launches++; } else { stats->extend_ms += t; stats->extend_launches++; }
         }
-#ifdef MIRT_STAMPS
-        {
-            unsigned long long hs[16];
-            HIPCHK(c, hipMemcpy(hs, d_stamps, sizeof hs, hipMemcpyDeviceToHost));
-            static const char *nm[8] = { "load+wait", "extend+classify", "coop draws", "finish+rad store", "barrier A", "atomic+barrier B", "queue store+barrier C", "loop overhead" };
-            unsigned long long tot = 0; for (int k = 0; k < 8; ++k) tot += hs[k];
-            fprintf(stderr, "[stamps] waves %llu, cycles/wave %.0f\n", hs[8], hs[8] ? (double)tot / hs[8] : 0.0);
-            for (int k = 0; k < 8; ++k) fprintf(stderr, "[stamps] %-22s %6.2f %%\n", nm[k], tot ? 100.0 * hs[k] / tot : 0.0);
-        }
-#endif
         stats->samples = npix_total * spp_count;
         stats->rays = stats->samples;                                  // bounce 0 traces one ray per sample
         stats->depth_hist[0] = stats->samples;

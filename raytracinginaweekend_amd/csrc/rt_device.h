@@ -1,4 +1,4 @@
-// rt_device.h -- gfx950 device functions of the wavefront path tracer: float3 math in the
+// rt_device.h -- gfx950 device functions of the path tracer: float3 math in the
 // reference's operation order, Philox4x32-10, the Randomizer mappings, intersection and scatter.
 //
 // Everything here is compiled with -ffp-contract=off: the reference is MSVC /fp:precise on the

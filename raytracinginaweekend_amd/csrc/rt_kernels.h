@@ -1,9 +1,13 @@
-// rt_kernels.h -- the gfx950 kernels of the wavefront path tracer.
+// rt_kernels.h -- the gfx950 kernels of the path tracer.
 //
-// Pipeline of one batch (a run of pixels x a run of samples, one path per (pixel, sample)):
+// One batch = a run of pixels x a run of samples, one path per (pixel, sample).  Two engines trace it, with the
+// same per-path arithmetic and Philox keys (identical images):
 //
-//   k_bounce<FIRST>   depth 0: ray generation fused with the first extend+shade
-//   k_bounce          depth 1..max_depth: extend (closest hit) + shade (scatter) of the live paths
+//   k_trace / k_trace_bvh   (default) persistent, one path per lane from camera ray to termination; a finished
+//                           lane takes a fresh camera ray from its wave's LDS stash.  No path state in HBM.
+//   k_bounce<FIRST>, k_bounce   the wavefront formulation: one launch per depth over compacted path queues
+//                           (three float4 planes per slot, ballot + prefix popcount, chunked slot reservations).
+//
 //   k_accumulate      ordered per-pixel sum of the batch's per-sample radiance
 //   k_resolve         mean, sqrt gamma, clamp, RGBA8  (once per image)
 //
@@ -12,12 +16,7 @@
 // HomemadeRayTracer.cpp:186), so each path writes one float4 into rad[] when it terminates and
 // k_accumulate adds the samples of a pixel in sample order -- the same order as the reference's
 // `col += Sample(r, 0)` loop (HomemadeRayTracer.cpp:126-133).  No float atomics, no run-to-run
-// variation.
-//
-// Live paths are kept dense: each bounce reads queue `in` (three float4 planes per slot: origin,
-// direction, throughput, pixel, sample; lane i reads element base+i of each plane, fully coalesced)
-// and the survivors are appended to queue `out` with a wave ballot + prefix popcount; output slots
-// come from chunks a workgroup reserves with one atomic per ~16 tiles.
+// variation, and no dependence on which lane or launch traced a path.
 #pragma once
 #include "rt_device.h"
 
@@ -75,9 +74,6 @@ struct BounceArgs {
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
     uint32_t depth, max_depth, flags, k0, k1;
-#ifdef MIRT_STAMPS
-    unsigned long long *stamps;   // diagnostic build only: per-segment wave-cycle sums (see tools/)
-#endif
 };
 
 // MIRT_EXP: ablation bits for timing experiments on the depth>=1 kernel (tools/ablate.sh); never set in the product
@@ -85,17 +81,6 @@ struct BounceArgs {
 #define MIRT_EXP 0
 #endif
 #define EXP_ON(bit) (!FIRST && (MIRT_EXP & (bit)))
-#ifdef MIRT_STAMPS
-#define STAMP_DECL unsigned long long st_prev = __builtin_readcyclecounter(), st_acc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
-#define STAMP(k) do { unsigned long long st_now = __builtin_readcyclecounter(); st_acc[k] += st_now - st_prev; st_prev = st_now; } while (0)
-#define STAMP_FLUSH do { if (lane == 0 && a.stamps) { for (int k_ = 0; k_ < 8; ++k_) atomicAdd(a.stamps + k_, st_acc[k_]); atomicAdd(a.stamps + 8, 1ull); } } while (0)
-#define STAMP_VMWAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define STAMP_DECL
-#define STAMP(k)
-#define STAMP_FLUSH
-#define STAMP_VMWAIT
-#endif
 
 // ---------------------------------------------------------------------------------- LDS staging
 struct LdsView {
@@ -439,7 +424,6 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
     const uint32_t chunk = 1u << a.chunk_shift;
     // thread 0's view of the workgroup's open out-chunk [ck_base, ck_base + chunk), filled up to ck_next
     uint32_t ck_base = 0xFFFFFFFFu, ck_next = 0, blk_alive = 0, par = 0;
-    STAMP_DECL;
 
     for (;;) {
       if (threadIdx.x == 0) s_work = atomicAdd(a.cursor, 1u);
@@ -454,7 +438,6 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
       const uint64_t uend = ubase + (1ull << ush);
       const uint32_t stop = (uint32_t)(filled < uend ? filled : uend);
       for (uint32_t base = (uint32_t)ubase; base < stop; base += MIRT_BLOCK) {
-        STAMP(7);
         const uint32_t idx = base + threadIdx.x;
         const bool active = idx < stop;
         f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
@@ -473,7 +456,6 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
                 }
             }
         }
-        STAMP_VMWAIT; STAMP(0);
         // -------- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
         bool done = false;                    // path ends at this vertex with `radiance`
         f3 radiance = mk(0.0f, 0.0f, 0.0f);
@@ -502,12 +484,10 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
                 }
             }
         }
-        STAMP(1);
         // -------- phase 2 (whole wave): the draws of Scatter
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
         if (EXP_ON(2)) { sp = mk(0.1f, 0.2f, 0.3f); un = 0.5f; }
         else coop_draws<false>(s_coop[wave], lane, need, pixel, sample, 1u + a.depth, a.k0, a.k1, sp, un);
-        STAMP(2);
         // -------- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         bool alive = false;
         f3 no = o, nd = d;
@@ -522,14 +502,12 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
             a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
         }
-        STAMP(3);
         // -------- compaction: wave ballot + prefix popcount; slots come from the workgroup's open chunk
         const unsigned long long m = __ballot(alive);
         const uint32_t wcnt = (uint32_t)__popcll(m);
         const uint32_t wpre = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) s_wcnt[par][wave] = wcnt;
         __syncthreads();
-        STAMP(4);
         if (threadIdx.x == 0) {
             uint32_t tot = 0;
 #pragma unroll
@@ -547,7 +525,6 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             s_base[par] = at;
         }
         __syncthreads();
-        STAMP(5);
         const uint32_t sb = s_base[par];
         if (EXP_ON(16)) asm volatile("" :: "v"(no.x), "v"(no.y), "v"(no.z), "v"(nd.x), "v"(nd.y), "v"(nd.z), "v"(thr.x), "v"(thr.y), "v"(thr.z));
         if (alive && sb != 0xFFFFFFFFu && !EXP_ON(16)) {
@@ -558,14 +535,12 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             a.out.p2[pos] = make_float4(thr.z, __uint_as_float(pixel), __uint_as_float(sample), 0.0f);
         }
         par ^= 1u;
-        STAMP(6);
       }
     }
     if (threadIdx.x == 0) {
         if (ck_base != 0xFFFFFFFFu) a.len_out[ck_base >> a.chunk_shift] = ck_next - ck_base;
         if (blk_alive) atomicAdd(a.alive_out, blk_alive);
     }
-    STAMP_FLUSH;
 }
 
 

@@ -11,10 +11,19 @@ WORLD_RANDOM_SPHERES, WORLD_CORNELL, WORLD_FOUR_SPHERES, WORLD_TWO_BOXES = 0, 1,
 _lib = None
 
 
+def ensure_built():
+    """The host layer is plain g++ (no hipcc): rebuild it in-tree if a fresh checkout lacks the binaries."""
+    libdir = os.path.dirname(capi.LIB_PATH)
+    if not all(os.path.exists(os.path.join(libdir, n)) for n in ("libmirt_host.so", "cornell_example", "flythrough")):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(os.path.dirname(libdir), "host")], check=True, stdout=subprocess.DEVNULL)
+
+
 def lib():
     global _lib
     if _lib is None:
         capi.load()
+        ensure_built()
         L = C.CDLL(LIB)
         L.mirt_host_world_create.argtypes = [C.c_int, C.c_float, C.c_uint64, C.c_char_p, C.c_size_t]; L.mirt_host_world_create.restype = C.c_void_p
         L.mirt_host_world_scene.argtypes = [C.c_void_p]; L.mirt_host_world_scene.restype = C.POINTER(capi.SceneStruct)

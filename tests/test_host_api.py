@@ -84,6 +84,7 @@ def test_traceray_through_the_cpp_api_matches_the_c_abi(gpu, tmp_path):
 
 @pytest.mark.gpu
 def test_example_program_renders_a_ppm(tmp_path):
+    hostapi.ensure_built()
     exe = os.path.join(os.path.dirname(capi.LIB_PATH), "cornell_example")
     r = subprocess.run([exe, "64", "64", "4", str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
@@ -157,6 +158,7 @@ def test_progressive_passes_equal_one_render(gpu):
 
 @pytest.mark.gpu
 def test_flythrough_cli(tmp_path):
+    hostapi.ensure_built()
     exe = os.path.join(os.path.dirname(capi.LIB_PATH), "flythrough")
     r = subprocess.run([exe, "1", "48", "40", "3", "6", "4", str(tmp_path), "W,WL,-"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr + r.stdout
