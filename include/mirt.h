@@ -139,7 +139,7 @@ void        mirt_destroy(mirt_ctx *ctx);                 /* HomemadeRayTracer::O
 const char *mirt_last_error(const mirt_ctx *ctx);        /* ctx may be NULL: last create error */
 int         mirt_device_count(void);
 /* option names:
- *  "max_paths"      paths per batch (default 256 Mi; buffers are sized by the render at hand, up to this)
+ *  "max_paths"      paths per batch (default 1 Gi; buffers are sized by the render at hand, up to this)
  *  "time_launches"  0/1: bracket every tracing-kernel launch with HIP events, sums reported in mirt_stats
  *  "engine"         1 (default): persistent kernel, one path per lane, no path queues;
  *                   0: wavefront formulation, one launch per bounce over compacted path queues.

@@ -45,7 +45,7 @@ struct mirt_ctx {
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
-    uint64_t max_paths = 256ull << 20;      // 256 Mi paths: 2 x 13.8 GB queues + 4.3 GB radiance slots when fully used
+    uint64_t max_paths = 1ull << 30;        // 1 Gi paths per batch = 17 GB of radiance slots when fully used (a batch costs ~0.3 ms of tail)
     bool time_launches = false;
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
@@ -444,8 +444,8 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     if (c->engine == 1) return render_persistent(c, p, d_sum, st, stats, mode, spp_begin, spp_count, one_spp);
     if (c->sc.n_textures) return fail(c, MIRT_ERR_STATE, "mirt_render_device: the wavefront engine (option engine=0) renders single-colour scenes only; this scene has image textures");
 
-    // batch geometry: npix_b pixels x S samples <= capacity
-    const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
+    // batch geometry: npix_b pixels x S samples <= capacity (the queues cost 96 B per path: at most 256 Mi paths here)
+    const uint64_t cap = std::min<uint64_t>(std::min<uint64_t>(c->max_paths, 256ull << 20), npix_total * spp_count);
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
     const size_t capq = (size_t)npix_b * S;
