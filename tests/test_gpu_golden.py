@@ -115,3 +115,23 @@ def test_full_size_properties(gpu):
     c = gpu.render(1200, 800, 2, 50, 1, capi.FLAG_ACCEL_AUTO)
     assert np.isfinite(c["sum"]).all() and 2.4 < c["stats"].rays / c["stats"].samples < 3.0
     assert np.allclose(c["pixels"][0, 0], np.sqrt(np.float32([0.85, 0.9, 1.0])), atol=1e-6)
+
+
+def test_c5_frame_size(gpu):
+    """BASELINE config 5 is 4096^2: the frame renders (2 spp here), sample ranges and pixel/sample tilings compose exactly,
+    and a 1024^2 crop of samples is the same image whichever way the batches were cut (16.8 M pixels x 2 spp = 33.5 M paths)."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w = h = 4096
+    a = gpu.render(w, h, 2, 50, 5, capi.FLAG_ACCEL_AUTO, want=("sum",))
+    assert a["stats"].samples == w * h * 2 and 6.4 < a["stats"].rays / a["stats"].samples < 6.7 and a["stats"].batches == 1
+    try:
+        gpu.set_option("max_paths", 5_000_011)                           # pixel tiles of 5,000,011 pixels, one sample each
+        b = gpu.render(w, h, 2, 50, 5, capi.FLAG_ACCEL_AUTO, want=("sum",))
+        assert b["stats"].batches == 8
+    finally:
+        gpu.set_option("max_paths", 1 << 30)
+    assert a["sum"].tobytes() == b["sum"].tobytes() and a["stats"].rays == b["stats"].rays
+    c0 = gpu.render_progressive(w, h, 0, 1, 50, 5, want=())
+    c1 = gpu.render_progressive(w, h, 1, 1, 50, 5, want=("sum",))
+    assert c1["sum"].tobytes() == a["sum"].tobytes() and c0["stats"].rays + c1["stats"].rays == a["stats"].rays

@@ -165,7 +165,7 @@ def test_batching_and_ranges(gpu, orc):
     a = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
     gpu.set_option("max_paths", 3 * w * h + 17)                  # sample tiles of 3
     b = gpu.render(w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
-    gpu.set_option("max_paths", 256 << 20)
+    gpu.set_option("max_paths", 1 << 30)
     H.assert_bits(a["sum"], ref["sum"], "pixel tiles"); H.assert_bits(b["sum"], ref["sum"], "sample tiles")
     osum, _ = orc.trace(s, cam, w, h, 12, 50, 7, capi.FLAG_ACCEL_LIST)
     H.assert_bits(ref["sum"], osum, "vs oracle")
@@ -264,9 +264,9 @@ def test_engines_identical(gpu, orc, world):
                 out[engine, flags] = gpu.render(w, h, 5, 50, 77, flags)
             gpu.set_option("max_paths", 2 * w * h + 3)                   # three sample tiles
             out[engine, "tiled"] = gpu.render(w, h, 5, 50, 77, capi.FLAG_ACCEL_LIST)
-            gpu.set_option("max_paths", 256 << 20)
+            gpu.set_option("max_paths", 1 << 30)
     finally:
-        gpu.set_option("engine", 1); gpu.set_option("max_paths", 256 << 20)
+        gpu.set_option("engine", 1); gpu.set_option("max_paths", 1 << 30)
     osum, ost = orc.trace(s, cam, w, h, 5, 50, 77, capi.FLAG_ACCEL_LIST)
     for key, g in out.items():
         if world != "two_boxes" or key[1] in (capi.FLAG_ACCEL_LIST, "tiled"):   # coplanar ties: see test_ordered_traversal_and_own_bvh
