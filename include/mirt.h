@@ -145,9 +145,10 @@ int         mirt_device_count(void);
  *                   0: wavefront formulation, one launch per bounce over compacted path queues.
  *                   Both produce the same bits.
  *  "blocks_per_cu"  workgroups per CU of the persistent grid (0 = occupancy query, default)
- *  "lds_budget", "stack_lds"  LDS plan of the next mirt_upload_scene: bytes per workgroup that the top of
- *                   the BVH may fill (default 8192), traversal-stack levels kept in LDS (default 8, the
- *                   rest spills to HBM) */
+ *                   0: wavefront formulation (single-colour scenes only; batches of at most 256 Mi paths)
+ *  "lds_budget", "stack_lds", "lds_mats"  LDS plan of the next mirt_upload_scene: bytes per workgroup up to which
+ *                   the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS (default 2,
+ *                   the rest spills to HBM), largest material table staged (default 1024 bytes) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 
 /* -- scene ---------------------------------------------------------------------------------- */
