@@ -70,6 +70,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        warm = torch.zeros(1, device=dev)
+        dist.all_reduce(warm)                        # creates the RCCL communicator here, not inside a timed step (--warmup 0)
+        dist.reduce(warm, dst=0)
+        torch.cuda.synchronize(dev)
 
     W, H, SPP = args.width, args.height, args.spp
     sc, cam = scene.cornell_box(W / H)
