@@ -6,7 +6,7 @@
 #include "AABB.h"
 #include "FlatScene.h"
 
-class Ray;
+struct Ray;
 class IMaterial;
 
 struct HitRecord

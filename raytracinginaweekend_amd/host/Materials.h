@@ -66,3 +66,43 @@ public:
 	static MaterialID GetStaticID() { return MID_DIFFUSE_LIGHT; }
 	FlatMaterial Flatten() const override;
 };
+
+// The slots of Resources' tables (RayTracer/RayTracer/Resouces.h:3-43): the enumerators are part of the scene API
+// (`GetTheMaterial(MATERIAL_ID_DIELECTRIC)`), and their order is the order Resources::LoadMaterials fills the table in.
+enum MeshUniqueID
+{
+	MESH_ID_HIGH_POLYGON_SPHERE = 0,
+	MESH_ID_MEDIUM_POLYGON_SPHERE,
+	MESH_ID_LOW_POLYGON_SPHERE,
+	MESH_ID_QUAD,
+	MESH_ID_CUBE,
+
+	MESH_ID_TOTAL_COUNT
+};
+
+enum MaterialUniqueID
+{
+	MATERIAL_ID_RANDOM_LAMBERTIAN_START = 0,
+	MATERIAL_ID_RANDOM_LAMBERTIAN_COUNT = 50,
+	MATERIAL_ID_RANDOM_METAL_START = MATERIAL_ID_RANDOM_LAMBERTIAN_START + MATERIAL_ID_RANDOM_LAMBERTIAN_COUNT,
+	MATERIAL_ID_RANDOM_METAL_COUNT = 50,
+	MATERIAL_ID_LAMBERTIAN0 = MATERIAL_ID_RANDOM_METAL_START + MATERIAL_ID_RANDOM_METAL_COUNT,
+	MATERIAL_ID_LAMBERTIAN1,
+	MATERIAL_ID_LAMBERTIAN2,
+	MATERIAL_ID_LAMBERTIAN3,
+	MATERIAL_ID_LAMBERTIAN4,
+	MATERIAL_ID_METAL,
+	MATERIAL_ID_DIELECTRIC,
+	MATERIAL_ID_IMAGE_BASED_GROUND_SOIL,
+	MATERIAL_ID_IMAGE_BASED_METAL_CHECKER,
+	MATERIAL_ID_LIGHTSOURCE_WHITE,
+	MATERIAL_ID_LIGHTSOURCE_BRIGHT,
+	MATERIAL_ID_LIGHTSOURCE_RED,
+	MATERIAL_ID_LIGHTSOURCE_GREEN,
+	MATERIAL_ID_LIGHTSOURCE_BLUE,
+	MATERIAL_ID_CORNELL_BALL1,
+	MATERIAL_ID_CORNELL_BALL2,
+
+	MATERIAL_ID_TOTAL_COUNT
+};
+

@@ -1,12 +1,3 @@
-// Ray.h -- RayTracer/RayTracer/Ray.h:5-18
+// Ray.h -- kept so that `#include "Ray.h"` of scene code written against the reference resolves; Ray lives beside Vec3.
 #pragma once
 #include "Vec3.h"
-
-class Ray
-{
-public:
-	Ray() = default;
-	Ray(const Vec3 &org, const Vec3 &dir) : m_org(org), m_dir(dir) {}
-	Vec3 PointAt(float t) const { return m_org + t * m_dir; }
-	Vec3 m_org, m_dir;
-};

@@ -62,3 +62,12 @@ inline Vec3 cross(const Vec3 &a, const Vec3 &b)
 }
 inline Vec3 normalize(const Vec3 &v) { Vec3 r = v; r.normalize(); return r; }
 inline Vec3 zero() { return Vec3(0.0f, 0.0f, 0.0f); }
+
+// Ray (RayTracer/RayTracer/Ray.h:5-18): origin + t * direction; the direction is not normalised.
+struct Ray
+{
+	Vec3 m_org, m_dir;
+	Ray() = default;
+	Ray(const Vec3 &org, const Vec3 &dir) : m_org(org), m_dir(dir) {}
+	Vec3 PointAt(float t) const { return m_org + t * m_dir; }
+};
