@@ -138,6 +138,7 @@ inline std::string validate(const mirt_scene &s)
     uint32_t next = 0;
     for (uint32_t o = 0; o < s.n_objects; ++o) {
         if (s.obj_first[o] != next || s.obj_count[o] == 0) return "objects must be consecutive non-empty runs of primitives";
+        if (s.obj_count[o] > s.n_prims - next) return "objects do not cover the primitives";
         next += s.obj_count[o];
         for (uint32_t i = 1; i < s.obj_count[o]; ++i)
             if (s.prim_kind[s.obj_first[o] + i] != MIRT_PRIM_RECT || s.prim_kind[s.obj_first[o]] != MIRT_PRIM_RECT) return "a multi-primitive object must be rects (HitableCombo of a cube)";

@@ -141,3 +141,39 @@ def test_image_writers(tmp_path):
         capi.write_image(str(tmp_path / "d.pfm"), capi.IMG_PFM, rgba8=rgba)                        # PFM needs floats
     with pytest.raises(capi.MirtError):
         capi.write_image(str(tmp_path / "nodir" / "e.ppm"), capi.IMG_P6, rgba8=rgba)
+
+
+def _sanitized(tmp_path, name, sources, extra):
+    exe = str(tmp_path / name)
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe] + sources + extra
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr:
+        pytest.skip("no sanitizer runtime for g++ here")
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_scene_validation_under_sanitizers(tmp_path):
+    """Host code that reads caller-supplied arrays (validate, prepare_tree, the SAH builder) on random scenes with corrupted
+    trees, object runs and material indices, built with ASan + UBSan: every scene is rejected or yields a valid tree."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = _sanitized(tmp_path, "fuzz_scene", [os.path.join(root, "tests", "fuzz", "fuzz_scene.cpp")], ["-I" + os.path.join(root, "raytracinginaweekend_amd", "csrc")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "accepted" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
+
+
+def test_tga_decoder_under_sanitizers(tmp_path):
+    """DecodeTGA on 20,000 mutations of valid files (all kinds, RLE, origins), ASan + UBSan: decodes or throws, never overruns."""
+    import itertools
+    from tests import helpers as H
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    host = os.path.join(root, "raytracinginaweekend_amd", "host")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    exe = _sanitized(tmp_path, "fuzz_tga", [os.path.join(root, "tests", "fuzz", "fuzz_tga.cpp"), os.path.join(host, "host.cpp")],
+                     ["-I" + host, "-L" + libdir, "-lmirt", "-Wl,-rpath," + libdir])
+    img = H.synthetic_texture(19, 11, 5, "checker")
+    seeds = []
+    for i, (k, rle, o) in enumerate(itertools.product(("rgb24", "rgb32", "gray", "cmap24", "cmap32"), (False, True), ("ll", "ur"))):
+        seeds.append(str(tmp_path / f"s{i}.tga")); H.write_tga(seeds[-1], img, k, rle, o)
+    r = subprocess.run([exe] + seeds, capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "decoded" in r.stdout, r.stdout[-500:] + r.stderr[-3000:]
