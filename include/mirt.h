@@ -99,7 +99,7 @@ typedef struct mirt_hit {
 #define MIRT_FLAG_NORMAL_DISPLAY 2u  /* m_enableNormalDisplay, HomemadeRayTracer.cpp:164-167 */
 #define MIRT_FLAG_ACCEL_LIST     4u  /* closest hit by a linear pass over all objects instead
                                         of the BVH (what HitableCombo::Hit does, Hitables.cpp:130-142) */
-#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for tiny scenes, ORDERED otherwise */
+#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for scenes of up to 48 primitives, ORDERED otherwise */
 #define MIRT_FLAG_ACCEL_ORDERED  32u /* walk the BVH nearer child first instead of the reference's
                                         left-then-right order (SimpleObject.cpp:394-402): same closest
                                         t, far fewer boxes; only the winner of an exact tie can differ.

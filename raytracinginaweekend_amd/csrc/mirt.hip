@@ -270,7 +270,7 @@ extern "C" int mirt_set_camera(mirt_ctx *c, const mirt_camera *cam)
 static int accel_mode(const mirt_ctx *c, uint32_t flags)
 {
     if (flags & MIRT_FLAG_ACCEL_LIST) return 0;
-    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 16 && c->prims_in_lds) ? 0 : 2;
+    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 48 && c->prims_in_lds) ? 0 : 2;
     if (flags & MIRT_FLAG_ACCEL_ORDERED) return 2;
     return 1;
 }
