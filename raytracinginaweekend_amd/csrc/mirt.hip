@@ -357,7 +357,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     const uint32_t n_s_tiles = (spp_count + S - 1) / S;
     const uint32_t n_batches = n_pix_tiles * n_s_tiles;
     const uint32_t per_cu = c->blocks_per_cu ? c->blocks_per_cu : trace_occupancy(c, mode);
-    if (getenv("MIRT_DEBUG")) fprintf(stderr, "[mirt] persistent engine, mode %d, lds %u B, %u workgroups/CU (occupancy query %u)\n", mode, mode == 2 ? c->lds_bytes2 : c->lds_bytes, per_cu, trace_occupancy(c, mode));
+    if (getenv("MIRT_DEBUG")) fprintf(stderr, "[mirt] persistent engine, mode %d, lds %u B, %u workgroups/CU (occupancy query %u)\n", mode, trace_lds(c, mode), per_cu, trace_occupancy(c, mode));
     const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
     const size_t per_batch = 66;                           // cursor, hist[65]
     if (c->d_rad.ensure(capq * sizeof(float4)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
