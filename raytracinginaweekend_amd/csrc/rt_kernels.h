@@ -346,11 +346,22 @@ __device__ __forceinline__ void generate_ray(const Args &a, uint32_t pixel, uint
 // takes the first accepted iteration, exactly the one its own loop would have stopped at.
 struct CoopLds { uint32_t pix[64], smp[64], it[64], stg[64]; };
 
-__device__ __forceinline__ f3 sphere_candidate(uint32_t pixel, uint32_t sample, uint32_t stage, uint32_t it, uint32_t k0, uint32_t k1)
+// Is the candidate (the first three words of a Philox block) inside the unit sphere?  The reference decides on
+// the mapped floats (Randomizer.h:43-46: reject while dot(p,p) >= 1), and mapping three words costs 21 f64
+// instructions.  A float estimate of the same coordinates is within 2^-23 of them, so its dot product is within
+// 2e-6 of the exact one: outside a band of 8e-6 around 1 the estimate decides, inside it (about one candidate in
+// 10^5) the exact arithmetic does.  Only the accepted candidate is mapped exactly, once, by its owner.
+__device__ __forceinline__ bool candidate_inside(const uint32_t r[4])
 {
-    uint32_t r[4];
-    philox4x32_10(pixel, sample, stage, it, k0, k1, r);
-    return mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
+    const float x = __builtin_fmaf((float)r[0], 0x1p-31f, -1.0f), y = __builtin_fmaf((float)r[1], 0x1p-31f, -1.0f),
+                z = __builtin_fmaf((float)r[2], 0x1p-31f, -1.0f);
+    const float s = (x * x + y * y) + z * z;
+    bool inside = s < 1.0f;
+    if (__builtin_fabsf(s - 1.0f) < 8e-6f) {
+        const f3 p = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
+        inside = !(dot(p, p) >= 1.0f);
+    }
+    return inside;
 }
 
 // need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this).
@@ -361,13 +372,14 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
 {
     bool pending = false;
     uint32_t next_it = 1;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;                            // the accepted candidate's raw words
     if (need != NEED_NONE) {                                    // round 0: block 0 serves all three materials
         uint32_t r[4];
         philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
         unorm = map_unorm(r[0]);
         if (need == NEED_SPHERE) {
-            sphere_pt = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
-            pending = dot(sphere_pt, sphere_pt) >= 1.0f;
+            w0 = r[0]; w1 = r[1]; w2 = r[2];
+            pending = !candidate_inside(r);
         }
     }
     unsigned long long mask;
@@ -381,13 +393,13 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t e = lane >> lg, sub = lane & (G - 1u);
-        f3 c = mk(0.0f, 0.0f, 0.0f);
+        uint32_t r[4] = { 0u, 0u, 0u, 0u };
         bool acc = false;
         if (e < n) {
             uint32_t it = cl.it[e] + sub;
             if (it < MIRT_REJECT_CAP) {
-                c = sphere_candidate(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1);
-                acc = !(dot(c, c) >= 1.0f) || it == MIRT_REJECT_CAP - 1u;        // the cap keeps its last candidate, like the per-lane loop
+                philox4x32_10(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1, r);
+                acc = candidate_inside(r) || it == MIRT_REJECT_CAP - 1u;          // the cap keeps its last candidate, like the per-lane loop
             }
         }
         const unsigned long long am = __ballot(acc);
@@ -398,10 +410,11 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
             if (bits) { src = (rank << lg) + (uint32_t)__builtin_ctz(bits); got = true; }
             else next_it += G;
         }
-        float cx = __shfl(c.x, (int)src), cy = __shfl(c.y, (int)src), cz = __shfl(c.z, (int)src);
-        if (got) { sphere_pt = mk(cx, cy, cz); pending = false; }
+        const uint32_t c0 = (uint32_t)__shfl((int)r[0], (int)src), c1 = (uint32_t)__shfl((int)r[1], (int)src), c2 = (uint32_t)__shfl((int)r[2], (int)src);
+        if (got) { w0 = c0; w1 = c1; w2 = c2; pending = false; }
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
     }
+    if (need == NEED_SPHERE) sphere_pt = mk(map_pm1(w0), map_pm1(w1), map_pm1(w2));
 }
 
 // ---------------------------------------------------------------------------------- the bounce kernel
