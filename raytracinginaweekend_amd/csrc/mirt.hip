@@ -181,6 +181,8 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         MatRec &r = mats[m]; memset(&r, 0, sizeof r);
         r.kind = s->mat_kind[m]; r.fuzz = s->mat_fuzz[m]; r.ior = s->mat_ior[m];
         r.tex = (s->n_textures && s->mat_texture[m] >= 0) ? s->mat_texture[m] : -1;
+        r.inv_ior = 1.0f / r.ior;
+        r.r0 = schlick_r0(r.ior);                       // same IEEE divide and multiply as in the kernel (no contraction on either side)
         for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
     }
     if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||

@@ -141,7 +141,8 @@ struct MatRec {             // 48 B
     uint32_t kind; float albedo[3];
     float    fuzz, ior, emit[3];
     int32_t  tex;           // image texture sampled for the albedo, -1 = the single colour above
-    float    pad[2];
+    float    r0;            // Dielectric: ((1 - ior) / (1 + ior))^2 of Schlick (Optics.h:29-30), a per-material constant
+    float    inv_ior;       // Dielectric: 1.0f / ior (Materials.cpp:193), likewise
 };
 struct TexRec { uint32_t w, h, offset, pad; };   // offset: first texel in the RGBA8 texel array
 #define PI_KIND(i)   ((i) & 1u)
@@ -299,12 +300,12 @@ __device__ __forceinline__ bool refract(f3 v, f3 n, float ni_over_nt, f3 &refrac
 }
 // Optics.h:27-32; pow(float,int) -> x^5 in double rounded once, as the oracle defines it.
 __device__ __forceinline__ float pow5f(float x) { double d = x, d2 = d * d, d4 = d2 * d2; return (float)(d4 * d); }
-__device__ __forceinline__ float schlick(float cosine, float ref_idx)
+__host__ __device__ __forceinline__ float schlick_r0(float ref_idx)
 {
     float r0 = (1 - ref_idx) / (1 + ref_idx);
-    r0 = r0 * r0;
-    return r0 + (1 - r0) * pow5f(1 - cosine);
+    return r0 * r0;
 }
+__device__ __forceinline__ float schlick(float cosine, float r0) { return r0 + (1 - r0) * pow5f(1 - cosine); }
 
 // ----------------------------------------------------------------------------- Materials.cpp
 // Scatter is split in three so the render kernel can draw for a whole wavefront at once:
@@ -375,8 +376,8 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
             o.atten = mk(1.0f, 1.0f, 1.0f);
             float dn = dot(uv, nrm);
             if (dn > 0) { outward = neg(nrm); ni_over_nt = ior; cosine = ior * dn; }
-            else { outward = nrm; ni_over_nt = 1.0f / ior; cosine = -dn; }
-            if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, ior);
+            else { outward = nrm; ni_over_nt = m.inv_ior; cosine = -dn; }
+            if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.r0);
             else reflect_prob = 1.0f;
             o.dir = (unorm < reflect_prob) ? refl : refracted;
             o.alive = true;
