@@ -215,3 +215,19 @@ def test_object_bounds_and_bvh_shape():
     assert mn[6][1] == pytest.approx(-1.0001, abs=1e-6) and mx[6][0] - mn[6][0] > 0.6          # rotated cube: wider than its side
     n = orc.bvh_build_reference(s, np.zeros(64, np.uint32))                                     # all draws 0 -> axis x everywhere
     assert n == 7 and s.nodes[4] == 0
+
+
+def test_random_scenes_bvh_equals_list():
+    """Random mixtures of every primitive kind: the reference-shaped tree and the plain list give the same closest t."""
+    from tests.test_gpu_parity import random_scene
+    for seed in range(6):
+        s, cam = random_scene(100 + seed)
+        draws = np.random.default_rng(seed).integers(0, 2 ** 32, 4 * s.n_objects + 8, dtype=np.uint64).astype(np.uint32)
+        orc.bvh_build_reference(s, draws)
+        org, d = H.ray_batch(4096, 40 + seed, extent=5.0)
+        a, _ = orc.world_hit_batch(s, org, d, 0.001, float(np.finfo(np.float32).max), 0)
+        b, _ = orc.world_hit_batch(s, org, d, 0.001, float(np.finfo(np.float32).max), orc.FLAG_ACCEL_LIST)
+        assert (a["prim"] >= 0).sum() > 300
+        H.assert_bits(a["t"], b["t"], f"seed {seed}")
+        img, st = orc.trace(s, cam, 24, 16, 2, 50, seed, 0)
+        assert np.isfinite(img).all() and st.rays >= 24 * 16 * 2
