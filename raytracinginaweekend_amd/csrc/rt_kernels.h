@@ -579,7 +579,7 @@ struct TraceArgs {
 // the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
 // outnumber what is left (BVH walks: iterations are long, LDS is what limits residency).
 template <int N>
-struct StashLds { float ox[N], oy[N], oz[N], dx[N], dy[N], dz[N]; uint32_t id[N], sl[N]; };
+struct StashLds { float4 a[N], b[N]; };   // a = (ox, oy, oz, dx), b = (dy, dz, path id, sample of the batch): two 16-byte LDS accesses per ray
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -634,8 +634,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         f3 go, gd;
                         generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
                         const uint32_t e = cnt + lane;
-                        stash.ox[e] = go.x; stash.oy[e] = go.y; stash.oz[e] = go.z;
-                        stash.dx[e] = gd.x; stash.dy[e] = gd.y; stash.dz[e] = gd.z; stash.id[e] = id; stash.sl[e] = sl;
+                        stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
+                        stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
                     w_next += g; cnt += g;
                     wave_lds_sync();
@@ -647,8 +647,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
                 if (!live && rank < cnt) {
                     const uint32_t e = cnt - 1u - rank;
-                    o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
-                    const uint32_t sl = stash.sl[e];
+                    const float4 qa = stash.a[e], qb = stash.b[e];
+                    o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
+                    const uint32_t sl = __float_as_uint(qb.w);
                     sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
                     thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                 }
@@ -668,8 +669,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     const uint32_t take = (n_idle - served < cnt) ? n_idle - served : cnt;
                     if (!live && rank >= served && rank < served + take) {
                         const uint32_t e = cnt - 1u - (rank - served);
-                        o = mk(stash.ox[e], stash.oy[e], stash.oz[e]); d = mk(stash.dx[e], stash.dy[e], stash.dz[e]); pid = stash.id[e];
-                        const uint32_t sl = stash.sl[e];
+                        const float4 qa = stash.a[e], qb = stash.b[e];
+                        o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
+                        const uint32_t sl = __float_as_uint(qb.w);
                         sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
                         thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                     }
@@ -689,8 +691,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
                         f3 go, gd;
                         generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
-                        stash.ox[lane] = go.x; stash.oy[lane] = go.y; stash.oz[lane] = go.z;
-                        stash.dx[lane] = gd.x; stash.dy[lane] = gd.y; stash.dz[lane] = gd.z; stash.id[lane] = id; stash.sl[lane] = sl;
+                        stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
+                        stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
                     w_next += g; cnt = g;
                     wave_lds_sync();
