@@ -50,6 +50,7 @@ struct mirt_ctx {
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
+    uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
     uint32_t stack_lds = 2;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
@@ -119,6 +120,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "time_launches")) { c->time_launches = value != 0; return MIRT_OK; }
     if (!strcmp(name, "lds_budget")) { if (value < 4096 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_budget out of range"); c->lds_budget = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "engine")) { if (value < 0 || value > 1) return fail(c, MIRT_ERR_ARG, "engine must be 0 (wavefront) or 1 (persistent)"); c->engine = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "lds_prims")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_prims out of range"); c->lds_prims = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
@@ -225,7 +227,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.spill = nullptr; d.spill_stride = 0;
     uint32_t used = d.stack_lds * MIRT_BLOCK * 4u;
     d.lds_mats = (s->n_mats * sizeof(MatRec) <= c->lds_mats) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
-    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= 4u * 1024u;       // scenes the list walk is meant for; larger ones keep the LDS for residency
+    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= c->lds_prims;       // scenes the list walk is meant for; larger ones keep the LDS for residency
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
     const uint32_t room_bytes = used < budget ? budget - used : 0u;
     c->sc2 = d;
