@@ -714,8 +714,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         bool done = false;
         f3 radiance = mk(0.0f, 0.0f, 0.0f);
         uint32_t need = NEED_NONE;
-        Hit h; h.pos = o; h.nrm = d; h.mat = 0;
-        const MatRec *M = a.sc.mats;
+        Hit h;                                 // set where `need`/`done` are decided below; read only under `live && !done`
+        const MatRec *M;
         if (live) {
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
