@@ -312,7 +312,7 @@ __device__ __forceinline__ float schlick(float cosine, float r0) { return r0 + (
 //   scatter_need   what the material wants from the RNG (nothing / a unit-sphere point / one unorm)
 //   (the draws)    per lane in the function-level hooks, wave-cooperative in k_bounce
 //   scatter_finish the rest of Scatter, given the draws
-struct Scat { bool alive; f3 atten, dir, emitted; };
+struct Scat { bool alive, emits; f3 atten, dir, emitted; };
 enum { NEED_NONE = 0, NEED_SPHERE = 1, NEED_UNORM = 2 };
 
 // lazy: with a stateless keyed source an absorbed Lambertian path (Materials.cpp:32 decides
@@ -350,12 +350,18 @@ __device__ __forceinline__ f3 albedo_of(const M &m, const TexRec *texs, const ui
 }
 
 // albedo: what the material's texture returns at the hit (albedo_of, or the single colour when the scene has no images)
-template <class M>
+// DEFAULTS: also give the fields a material does not touch their values of the reference (zero: the caller's
+// `emmitted.zero()`, HomemadeRayTracer.cpp:173, and the default-constructed outputs).  The render kernel passes false
+// and reads atten/dir only when alive, emitted only when emits -- which saves it the register moves.
+template <bool DEFAULTS = true, class M>
 __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
 {
-    o.emitted = mk(0.0f, 0.0f, 0.0f);                                   // HomemadeRayTracer.cpp:173
-    o.atten = mk(0.0f, 0.0f, 0.0f);
-    o.dir = mk(0.0f, 0.0f, 0.0f);
+    if (DEFAULTS) {
+        o.emitted = mk(0.0f, 0.0f, 0.0f);                               // HomemadeRayTracer.cpp:173
+        o.atten = mk(0.0f, 0.0f, 0.0f);
+        o.dir = mk(0.0f, 0.0f, 0.0f);
+    }
+    o.emits = false;
     uint32_t kind = m.kind;
     if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
         o.alive = dot(dir_in, nrm) < 0;
@@ -384,7 +390,7 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
         }
     } else {                                                            // DiffuseLight, Materials.cpp:260-264
         o.emitted = mk(m.emit[0], m.emit[1], m.emit[2]);
-        o.alive = false;
+        o.alive = false; o.emits = true;
     }
 }
 

@@ -712,7 +712,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 
         // ---- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
         bool done = false;
-        f3 radiance = mk(0.0f, 0.0f, 0.0f);
+        f3 radiance;                           // set wherever `done` is
         uint32_t need = NEED_NONE;
         Hit h;                                 // set where `need`/`done` are decided below; read only under `live && !done`
         const MatRec *M;
@@ -729,7 +729,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
                     radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done = true;
                 } else if (!(depth < a.max_depth)) {                               // :173-174
-                    done = true;
+                    radiance = mk(0.0f, 0.0f, 0.0f); done = true;
                 } else {
                     M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
                     need = scatter_need(M->kind, d, h.nrm, true);
@@ -743,9 +743,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         if (live && !done) {
             Scat s;
             const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
-            scatter_finish(*M, albedo, d, h.pos, h.nrm, sp, un, s);
+            scatter_finish<false>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
-            else { radiance = thr * s.emitted; done = true; }
+            else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
         if (live && done) {
             a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
