@@ -23,6 +23,9 @@
 namespace mirt {
 
 #define MIRT_BLOCK 256
+#ifndef MIRT_BVH_WAVES
+#define MIRT_BVH_WAVES 8   // waves per SIMD the BVH kernels are compiled for (register cap 512 / MIRT_BVH_WAVES)
+#endif
 
 // A path queue: three planes of float4 per slot -- (ox,oy,oz,dx) (dy,dz,tr,tg) (tb,pixel,sample,-) -- so a
 // path moves with three 16-byte accesses per lane, each perfectly coalesced (lane i at base + 16*i).
@@ -716,6 +719,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         uint32_t need = NEED_NONE;
         Hit h;                                 // set where `need`/`done` are decided below; read only under `live && !done`
         const MatRec *M;
+        if constexpr (ACCEL != 0) { h.pos = o; h.nrm = d; h.mat = 0; M = a.sc.mats; radiance = mk(0.0f, 0.0f, 0.0f); }   // under the 64-register cap of the BVH kernels defined values allocate better (fewer spills)
         if (live) {
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
@@ -743,7 +747,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         if (live && !done) {
             Scat s;
             const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
-            scatter_finish<false>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
+            scatter_finish<ACCEL != 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
@@ -764,7 +768,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 template <bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
 template <int ACCEL, bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK, 8) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
+__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
