@@ -40,7 +40,7 @@ struct mirt_ctx {
     uint32_t lds_bytes = 0, lds_bytes2 = 0, lds_stack_bytes = 0;   // the stack comes last in the plan: the list walk launches without it
     bool prims_in_lds = false;
     mirt_camera cam{};
-    DevBuf d_prims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
+    DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -99,7 +99,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -159,6 +159,24 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
             for (int i = 0; i < 6; ++i) r.rot[i] = chain ? q[i] : ((i & 1) ? 1.0f : 0.0f);
         }
     }
+    // The list walk's copy: stable-sorted by class so that each class is one tight loop (rt_kernels.h closest_list);
+    // .mat carries the primitive's own index, which is what acceptance and the caller need.
+    auto list_class = [](const PrimRec &r) -> uint32_t {
+        if (PI_ROT(r.info)) return 4u;
+        if (PI_KIND(r.info) == MIRT_PRIM_SPHERE) return 3u;
+        const uint32_t a = PI_AAX(r.info), b = PI_BAX(r.info), cc = PI_CAX(r.info);
+        if (a == 0 && b == 1 && cc == 2) return 0u;
+        if (a == 0 && b == 2 && cc == 1) return 1u;
+        if (a == 2 && b == 1 && cc == 0) return 2u;
+        return 4u;
+    };
+    std::vector<PrimRec> lprims; lprims.reserve(s->n_prims);
+    uint32_t lend[4] = { 0, 0, 0, 0 };
+    for (uint32_t cls = 0; cls < 5; ++cls) {
+        for (uint32_t p = 0; p < s->n_prims; ++p)
+            if (list_class(prims[p]) == cls) { lprims.push_back(prims[p]); lprims.back().mat = p; }
+        if (cls < 4) lend[cls] = (uint32_t)lprims.size();
+    }
     std::vector<NodeRec> nodes(tree.box.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         for (int a = 0; a < 3; ++a) { nodes[i].mn[a] = tree.box[i].mn[a]; nodes[i].mx[a] = tree.box[i].mx[a]; }
@@ -187,11 +205,12 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         r.r0 = schlick_r0(r.ior);                       // same IEEE divide and multiply as in the kernel (no contraction on either side)
         for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
     }
-    if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
+    if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_lprims.ensure(lprims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
         c->d_nodes2.ensure(nodes2.size() * sizeof(Node2)) ||
         c->d_objs.ensure(objs.size() * sizeof(uint2)) || c->d_mats.ensure(mats.size() * sizeof(MatRec)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
     HIPCHK(c, hipMemcpy(c->d_prims.p, prims.data(), prims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_lprims.p, lprims.data(), lprims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_nodes2.p, nodes2.data(), nodes2.size() * sizeof(Node2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_objs.p, objs.data(), objs.size() * sizeof(uint2), hipMemcpyHostToDevice));
@@ -212,6 +231,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         d.texs = (const TexRec *)c->d_texs.p; d.texels = (const uint32_t *)c->d_texels.p;
     }
     d.prims = (const PrimRec *)c->d_prims.p; d.n_prims = s->n_prims;
+    d.lprims = (const PrimRec *)c->d_lprims.p; for (int i = 0; i < 4; ++i) d.lend[i] = lend[i];
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;

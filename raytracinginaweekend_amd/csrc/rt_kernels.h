@@ -35,6 +35,7 @@ struct PathQ {
 
 struct SceneDev {
     const PrimRec *prims;  uint32_t n_prims;
+    const PrimRec *lprims; uint32_t lend[4];     // the list walk's copy, sorted by class (closest_list); .mat = index in `prims`
     const NodeRec *nodes;  uint32_t n_nodes;     // the tree as given (or built), walked in the reference's order
     const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
     uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
@@ -140,27 +141,52 @@ __device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
 //    Which root is taken does not depend on t_max (the second root is never smaller than the first), and a
 //    parked sphere is accepted under the sequential rule "t <= t_max, later index wins a tie" restated with
 //    the index: t < t_max || (t == t_max && index > best).
+// One class of the sorted list: unrotated rects whose axis triple is (A, B, C).  Branch-free on purpose: with 64
+// unrelated rays some lane always passes the t test, so skipping a/b buys nothing and the selects keep the loop
+// free of phi copies.  pr.mat of the sorted copy holds the primitive's index in the scene's own order.
 template <int A, int B, int C>
-__device__ __forceinline__ bool rect_t(const PrimRec &pr, f3 o, f3 d, float t_min, float t_max, float &t_out)
+__device__ __forceinline__ void rect_run(const SceneDev &sc, uint32_t &p, uint32_t end, f3 o, f3 d,
+                                         float t_min, float &t_max, int32_t &best)
 {
-    const float oc = C == 0 ? o.x : (C == 1 ? o.y : o.z), dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
-    float t = (pr.gb[1] - oc) / dc;                                     // Hitables.cpp:95
-    if (t <= t_max && t >= t_min) {
-        const float oa = A == 0 ? o.x : (A == 1 ? o.y : o.z), da = A == 0 ? d.x : (A == 1 ? d.y : d.z);
-        const float ob = B == 0 ? o.x : (B == 1 ? o.y : o.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
-        float a = oa + t * da;
-        float b = ob + t * db;
-        if (a >= pr.ga[0] && a <= pr.ga[1] && b >= pr.ga[2] && b <= pr.gb[0]) { t_out = t; return true; }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const float dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
+    const float da = A == 0 ? d.x : (A == 1 ? d.y : d.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
+    for (; p < end; ++p) {
+        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
+        const u32x4 q0 = q[0], q1 = q[1];
+        const u32x2 q2 = *(const __attribute__((address_space(4))) u32x2 *)(q + 2);
+        const f3 ol = o - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        const int32_t idx = (int32_t)q1.w;
+        const float oc = C == 0 ? ol.x : (C == 1 ? ol.y : ol.z);
+        const float oa = A == 0 ? ol.x : (A == 1 ? ol.y : ol.z), ob = B == 0 ? ol.x : (B == 1 ? ol.y : ol.z);
+        const float t = (__uint_as_float(q2.y) - oc) / dc;                 // Hitables.cpp:95
+        const float a = oa + t * da;
+        const float b = ob + t * db;
+        const bool in_t = t >= t_min && (t < t_max || (t == t_max && idx > best));
+        const bool in_ab = a >= __uint_as_float(q1.x) && a <= __uint_as_float(q1.y) && b >= __uint_as_float(q1.z) && b <= __uint_as_float(q2.x);
+        const bool hit = in_t & in_ab;
+        t_max = hit ? t : t_max;
+        best = hit ? idx : best;
     }
-    return false;
 }
 
+// The list is walked in class order (mirt.hip sorts a copy at upload: the three unrotated rect orientations, unrotated
+// spheres, everything else), each class by its own loop with the axes fixed at compile time and nothing to classify
+// per primitive.  Walking out of order is safe because acceptance carries the scene index:
+// "t <= t_max, a later primitive wins a tie" == "t < t_max || (t == t_max && index > best)" whatever the order.
 template <bool PLDS>
 __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
                                                 float t_min, float &t_max)
 {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     int32_t best = -1;
-    const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (spheres are never rotated)
+    uint32_t p = 0;
+    rect_run<0, 1, 2>(sc, p, sc.lend[0], o, d, t_min, t_max, best);
+    rect_run<0, 2, 1>(sc, p, sc.lend[1], o, d, t_min, t_max, best);
+    rect_run<2, 1, 0>(sc, p, sc.lend[2], o, d, t_min, t_max, best);
+
+    const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (unrotated spheres)
     bool pend = false; float p_nb = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;
     auto resolve = [&]() {
         if (pend) {
@@ -171,41 +197,31 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
             pend = false;
         }
     };
-    for (uint32_t p = 0; p < sc.n_prims; ++p) {
+    for (; p < sc.lend[3]; ++p) {
+        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
+        const u32x4 q0 = q[0], q1 = q[1];
+        const f3 oc = o - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+        const float b = 2.0f * dot(d, oc);
+        const float c = dot(oc, oc) - __uint_as_float(q1.z);
+        const float disc = b * b - four_a * c;
+        const bool cross = disc > 0;
+        if (__ballot(cross && pend) != 0ull) resolve();
+        if (cross) { pend = true; p_nb = -b; p_disc = disc; p_idx = (int32_t)q1.w; }
+    }
+    resolve();
+    for (; p < sc.n_prims; ++p) {
         // every lane walks the same primitive: the record comes through the scalar cache straight into SGPRs (s_load;
-        // the scene is read-only for the whole launch, so the constant address space is legitimate).  Against reading
-        // it from LDS this saves the per-read address moves and readfirstlanes: 157.0 -> 153.1 ms on the Cornell box.
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.prims + p);
+        // the scene is read-only for the whole launch, so the constant address space is legitimate).
+        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
         const u32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         PrimRec pr;
         pr.off[0] = __uint_as_float(q0.x); pr.off[1] = __uint_as_float(q0.y); pr.off[2] = __uint_as_float(q0.z); pr.info = q0.w;
         pr.ga[0] = __uint_as_float(q1.x); pr.ga[1] = __uint_as_float(q1.y); pr.ga[2] = __uint_as_float(q1.z); pr.mat = q1.w;
         pr.gb[0] = __uint_as_float(q2.x); pr.gb[1] = __uint_as_float(q2.y); pr.rot[0] = __uint_as_float(q2.z); pr.rot[1] = __uint_as_float(q2.w);
         pr.rot[2] = __uint_as_float(q3.x); pr.rot[3] = __uint_as_float(q3.y); pr.rot[4] = __uint_as_float(q3.z); pr.rot[5] = __uint_as_float(q3.w);
-        const uint32_t info = pr.info;
         float t;
-        bool hit;
-        if (PI_KIND(info) == MIRT_PRIM_SPHERE && !PI_ROT(info)) {
-            const f3 oc = o - mk(pr.off[0], pr.off[1], pr.off[2]);
-            const float b = 2.0f * dot(d, oc);
-            const float c = dot(oc, oc) - pr.ga[2];
-            const float disc = b * b - four_a * c;
-            const bool cross = disc > 0;
-            if (__ballot(cross && pend) != 0ull) resolve();
-            if (cross) { pend = true; p_nb = -b; p_disc = disc; p_idx = (int32_t)p; }
-            continue;
-        }
-        const uint32_t axes = (info >> 1) & 63u;                         // aAxis | bAxis << 2 | cAxis << 4
-        if (PI_KIND(info) != MIRT_PRIM_SPHERE && !PI_ROT(info) && (axes == (0u | 1u << 2 | 2u << 4) || axes == (0u | 2u << 2 | 1u << 4) || axes == (2u | 1u << 2 | 0u << 4))) {
-            const f3 ol = o - mk(pr.off[0], pr.off[1], pr.off[2]);
-            if (axes == (0u | 1u << 2 | 2u << 4)) hit = rect_t<0, 1, 2>(pr, ol, d, t_min, t_max, t);
-            else if (axes == (0u | 2u << 2 | 1u << 4)) hit = rect_t<0, 2, 1>(pr, ol, d, t_min, t_max, t);
-            else hit = rect_t<2, 1, 0>(pr, ol, d, t_min, t_max, t);
-        } else hit = prim_t(pr, o, d, t_min, t_max, t);
-        if (hit) { t_max = t; best = (int32_t)p; }
+        if (prim_t(pr, o, d, t_min, t_max, t) && (t < t_max || (int32_t)pr.mat > best)) { t_max = t; best = (int32_t)pr.mat; }
     }
-    resolve();
     return best;
 }
 
