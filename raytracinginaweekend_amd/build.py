@@ -18,7 +18,7 @@ LIB = os.path.join(LIBDIR, "libmirt.so")
 SOURCES = ["mirt.hip"]
 DEPS = ["mirt.hip", "rt_kernels.h", "rt_device.h", "scene_host.h", os.path.join("..", "..", "include", "mirt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
 
 
 def stale() -> bool:

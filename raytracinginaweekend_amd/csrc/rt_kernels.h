@@ -163,8 +163,8 @@ __device__ __forceinline__ void rect_run(const SceneDev &sc, uint32_t &p, uint32
         const float t = (__uint_as_float(q2.y) - oc) / dc;                 // Hitables.cpp:95
         const float a = oa + t * da;
         const float b = ob + t * db;
-        const bool in_t = t >= t_min && (t < t_max || (t == t_max && idx > best));
-        const bool in_ab = a >= __uint_as_float(q1.x) && a <= __uint_as_float(q1.y) && b >= __uint_as_float(q1.z) && b <= __uint_as_float(q2.x);
+        const bool in_t = (t >= t_min) & ((t < t_max) | ((t == t_max) & (idx > best)));
+        const bool in_ab = (a >= __uint_as_float(q1.x)) & (a <= __uint_as_float(q1.y)) & (b >= __uint_as_float(q1.z)) & (b <= __uint_as_float(q2.x));
         const bool hit = in_t & in_ab;
         t_max = hit ? t : t_max;
         best = hit ? idx : best;
@@ -187,14 +187,14 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     rect_run<2, 1, 0>(sc, p, sc.lend[2], o, d, t_min, t_max, best);
 
     const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (unrotated spheres)
-    bool pend = false; float p_nb = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;
+    float p_b = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;                  // the parked sphere: b, discriminant, index (-1: none)
     auto resolve = [&]() {
-        if (pend) {
+        if (p_idx >= 0) {
             const float sq = __builtin_sqrtf(p_disc);
-            float t = (p_nb - sq) / two_a;                               // Hitables.cpp:31
-            if (!(t >= t_min)) t = (p_nb + sq) / two_a;                  // :41
-            if (t >= t_min && (t < t_max || (t == t_max && p_idx > best))) { t_max = t; best = p_idx; }
-            pend = false;
+            float t = (-p_b - sq) / two_a;                               // Hitables.cpp:31
+            if (!(t >= t_min)) t = (-p_b + sq) / two_a;                  // :41
+            if ((t >= t_min) & ((t < t_max) | ((t == t_max) & (p_idx > best)))) { t_max = t; best = p_idx; }
+            p_idx = -1;
         }
     };
     for (; p < sc.lend[3]; ++p) {
@@ -205,8 +205,8 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         const float c = dot(oc, oc) - __uint_as_float(q1.z);
         const float disc = b * b - four_a * c;
         const bool cross = disc > 0;
-        if (__ballot(cross && pend) != 0ull) resolve();
-        if (cross) { pend = true; p_nb = -b; p_disc = disc; p_idx = (int32_t)q1.w; }
+        if (__ballot(cross & (p_idx >= 0)) != 0ull) resolve();
+        if (cross) { p_b = b; p_disc = disc; p_idx = (int32_t)q1.w; }
     }
     resolve();
     for (; p < sc.n_prims; ++p) {
