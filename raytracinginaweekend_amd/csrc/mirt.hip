@@ -247,7 +247,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.spill = nullptr; d.spill_stride = 0;
     uint32_t used = d.stack_lds * MIRT_BLOCK * 4u;
     d.lds_mats = (s->n_mats * sizeof(MatRec) <= c->lds_mats) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
-    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= c->lds_prims;       // scenes the list walk is meant for; larger ones keep the LDS for residency
+    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= c->lds_prims && d.lds_mats == s->n_mats;       // scenes the list walk is meant for; larger ones keep the LDS for residency
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
     const uint32_t room_bytes = used < budget ? budget - used : 0u;
     c->sc2 = d;

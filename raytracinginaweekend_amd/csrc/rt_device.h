@@ -277,8 +277,8 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
             h.u = (a - pr.ga[0]) / (pr.ga[1] - pr.ga[0]);
             h.v = (b - pr.ga[2]) / (pr.gb[0] - pr.ga[2]);
         }
-        h.nrm = mk(0.0f, 0.0f, 0.0f);
-        set(h.nrm, cA, PI_REV(info) ? -1.0f : 1.0f);
+        const float sgn = PI_REV(info) ? -1.0f : 1.0f;                   // selects, not the branches of set()
+        h.nrm = mk(cA == 0 ? sgn : 0.0f, cA == 1 ? sgn : 0.0f, cA >= 2 ? sgn : 0.0f);
         if (PI_ROT(info)) {
             rot_out(h.pos, h.nrm, 0, pr.rot[0], pr.rot[1]);
             rot_out(h.pos, h.nrm, 1, pr.rot[2], pr.rot[3]);

@@ -751,7 +751,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 } else if (!(depth < a.max_depth)) {                               // :173-174
                     radiance = mk(0.0f, 0.0f, 0.0f); done = true;
                 } else {
-                    M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
+                    // PLDS launches have the whole material table in LDS as well (mirt.hip): a plain LDS pointer, not a
+                    // per-lane choice between two address spaces (flat loads and 64-bit address arithmetic)
+                    if constexpr (PLDS) M = (const MatRec *)(lv.mats + h.mat);
+                    else M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
                     need = scatter_need(M->kind, d, h.nrm, true);
                 }
             }
