@@ -319,10 +319,9 @@ enum { NEED_NONE = 0, NEED_SPHERE = 1, NEED_UNORM = 2 };
 // independently of the draw) skips its draws; the explicit-stream hooks never skip.
 __device__ __forceinline__ uint32_t scatter_need(uint32_t kind, f3 dir_in, f3 nrm, bool lazy)
 {
-    if (kind == MIRT_MAT_LAMBERTIAN) return (lazy && !(dot(dir_in, nrm) < 0)) ? NEED_NONE : NEED_SPHERE;
-    if (kind == MIRT_MAT_METAL) return NEED_SPHERE;
-    if (kind == MIRT_MAT_DIELECTRIC) return NEED_UNORM;
-    return NEED_NONE;
+    const bool front = dot(dir_in, nrm) < 0;                                 // selects: the kinds of a wave are mixed anyway
+    const bool sphere = (kind == MIRT_MAT_METAL) | ((kind == MIRT_MAT_LAMBERTIAN) & (front | !lazy));
+    return sphere ? NEED_SPHERE : (kind == MIRT_MAT_DIELECTRIC ? NEED_UNORM : NEED_NONE);
 }
 
 // SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: nearest texel; float -> UINT32 as MSVC x64 does it
