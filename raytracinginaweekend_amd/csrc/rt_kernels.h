@@ -617,13 +617,20 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // TEX: the scene has image textures -- hits carry u,v (CalculateUV's atan2f/asinf for spheres) and the albedo is fetched
+#ifndef MIRT_LIST_STASH
+#define MIRT_LIST_STASH 128u
+#endif
+#ifndef MIRT_LIST_WAVES
+#define MIRT_LIST_WAVES 7
+#endif
 template <int ACCEL, bool PLDS, bool TEX>
 __device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
     constexpr bool BIG_STASH = ACCEL == 0;
-    __shared__ StashLds<BIG_STASH ? 128 : 64> s_stash[MIRT_BLOCK / 64];
+    constexpr uint32_t STASH_N = BIG_STASH ? MIRT_LIST_STASH : 64u;
+    __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
     __shared__ uint32_t s_hist[65];
 
     if ((uint64_t)blockIdx.x * a.claim >= a.n_paths) return;        // more workgroups than claims (uniform)
@@ -646,7 +653,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     for (;;) {
         if constexpr (BIG_STASH) {
             // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
-            if (cnt < 64u && !exhausted) {
+            if (cnt + 64u <= STASH_N && !exhausted) {
                 if (w_next == w_end) {
                     uint32_t b = 0;
                     if (lane == 0) b = atomicAdd(a.cursor, a.claim);
@@ -785,7 +792,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 // The list walk is VALU-bound and lives with 7 waves per SIMD; the BVH walks wait on node fetches, so they are
 // compiled for 8 waves per SIMD (<= 64 VGPRs; a three-dword spill) and launched with a small LDS plan.
 template <bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
+__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
 template <int ACCEL, bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
 
