@@ -405,10 +405,8 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         uint32_t r[4];
         philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
         unorm = map_unorm(r[0]);
-        if (need == NEED_SPHERE) {
-            w0 = r[0]; w1 = r[1]; w2 = r[2];
-            pending = !candidate_inside(r);
-        }
+        w0 = r[0]; w1 = r[1]; w2 = r[2];                       // read only when need == NEED_SPHERE
+        pending = (need == NEED_SPHERE) & !candidate_inside(r);
     }
     unsigned long long mask;
     while ((mask = __ballot(pending)) != 0ull) {
@@ -423,21 +421,16 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const uint32_t e = lane >> lg, sub = lane & (G - 1u);
         uint32_t r[4] = { 0u, 0u, 0u, 0u };
         bool acc = false;
-        if (e < n) {
-            uint32_t it = cl.it[e] + sub;
-            if (it < MIRT_REJECT_CAP) {
-                philox4x32_10(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1, r);
-                acc = candidate_inside(r) || it == MIRT_REJECT_CAP - 1u;          // the cap keeps its last candidate, like the per-lane loop
-            }
+        const uint32_t it = cl.it[e] + sub;                       // e < 64 always; entries >= n are stale and unused
+        if ((e < n) & (it < MIRT_REJECT_CAP)) {
+            philox4x32_10(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1, r);
+            acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
         }
         const unsigned long long am = __ballot(acc);
-        uint32_t src = lane;
-        bool got = false;
-        if (pending) {
-            uint32_t bits = (uint32_t)(am >> (rank << lg)) & ((1u << G) - 1u);     // this lane's G helpers, lowest = earliest iteration
-            if (bits) { src = (rank << lg) + (uint32_t)__builtin_ctz(bits); got = true; }
-            else next_it += G;
-        }
+        const uint32_t bits = (uint32_t)(am >> (rank << lg)) & ((1u << G) - 1u);   // this lane's G helpers, lowest = earliest iteration
+        const bool got = pending & (bits != 0u);
+        const uint32_t src = got ? (rank << lg) + (uint32_t)__builtin_ctz(bits | 0x80000000u) : lane;
+        next_it += (pending & !got) ? G : 0u;
         const uint32_t c0 = (uint32_t)__shfl((int)r[0], (int)src), c1 = (uint32_t)__shfl((int)r[1], (int)src), c2 = (uint32_t)__shfl((int)r[2], (int)src);
         if (got) { w0 = c0; w1 = c1; w2 = c2; pending = false; }
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
