@@ -275,18 +275,20 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
 // the reference's left-first order; only the winner of an exact tie in t can differ.
 __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, float &t_near)
 {
+    bool ok = true;                     // AABB.cpp:17's early return as one flag: once an axis fails the answer is false whatever follows
 #pragma unroll
     for (uint32_t a = 0; a < 3; ++a) {
         float id = get(invd, a);
         float t0 = (mn[a] - get(o, a)) * id;
         float t1 = (mx[a] - get(o, a)) * id;
-        if (id < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-        t_min = (t0 > t_min) ? t0 : t_min;
-        t_max = (t1 < t_max) ? t1 : t_max;
-        if (t_max <= t_min) return false;
+        const bool neg = id < 0.0f;
+        const float tn = neg ? t1 : t0, tf = neg ? t0 : t1;
+        t_min = (tn > t_min) ? tn : t_min;
+        t_max = (tf < t_max) ? tf : t_max;
+        ok &= !(t_max <= t_min);
     }
     t_near = t_min;
-    return true;
+    return ok;
 }
 
 template <bool PLDS>
@@ -310,7 +312,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
             }
             float tl = 0.0f, tr = 0.0f;
             const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, tl);
-            const bool hr = n.right != MIRT_CHILD_NONE && slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, tr);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, tr);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 const int32_t far = left_first ? n.right : n.left;
