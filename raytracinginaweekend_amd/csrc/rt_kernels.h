@@ -273,9 +273,13 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
 // current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
 // shrinks early and most of the far subtrees are culled by their box.  The closest t is the same as with
 // the reference's left-first order; only the winner of an exact tie in t can differ.
+// AABB::Hit's arithmetic with its control flow folded away, result unchanged:
+//  * (t0 > t_min) ? t0 : t_min is fmaxf(t0, t_min) and (t1 < t_max) ? t1 : t_max is fminf(t1, t_max): t_min/t_max are
+//    never NaN, and a NaN t0/t1 (0 * inf) is ignored by both forms;
+//  * t_min only grows and t_max only shrinks from axis to axis, so AABB.cpp:17's per-axis "t_max <= t_min -> miss"
+//    fires on some axis exactly when it fires on the final values: one compare instead of three early returns.
 __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, float &t_near)
 {
-    bool ok = true;                     // AABB.cpp:17's early return as one flag: once an axis fails the answer is false whatever follows
 #pragma unroll
     for (uint32_t a = 0; a < 3; ++a) {
         float id = get(invd, a);
@@ -283,12 +287,11 @@ __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f
         float t1 = (mx[a] - get(o, a)) * id;
         const bool neg = id < 0.0f;
         const float tn = neg ? t1 : t0, tf = neg ? t0 : t1;
-        t_min = (tn > t_min) ? tn : t_min;
-        t_max = (tf < t_max) ? tf : t_max;
-        ok &= !(t_max <= t_min);
+        t_min = __builtin_fmaxf(tn, t_min);
+        t_max = __builtin_fminf(tf, t_max);
     }
     t_near = t_min;
-    return ok;
+    return !(t_max <= t_min);
 }
 
 template <bool PLDS>
