@@ -229,23 +229,22 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
         float b = 2.0f * dot(d, o);
         float c = dot(o, o) - pr.ga[2];
         float disc = b * b - 4 * a * c;
-        if (disc > 0) {
+        bool in = false;
+        if (disc > 0) {                                                  // one exit, flags instead of early returns
             float sq = __builtin_sqrtf(disc);
             float t = (-b - sq) / (2.0f * a);
-            if (t <= t_max && t >= t_min) { t_out = t; return true; }
-            t = (-b + sq) / (2.0f * a);
-            if (t <= t_max && t >= t_min) { t_out = t; return true; }
+            in = (t <= t_max) & (t >= t_min);
+            if (!in) { t = (-b + sq) / (2.0f * a); in = (t <= t_max) & (t >= t_min); }
+            t_out = t;
         }
-        return false;
+        return in;
     }
     uint32_t aA = PI_AAX(info), bA = PI_BAX(info), cA = PI_CAX(info);
     float t = (pr.gb[1] - get(o, cA)) / get(d, cA);
-    if (t <= t_max && t >= t_min) {
-        float a = get(o, aA) + t * get(d, aA);
-        float b = get(o, bA) + t * get(d, bA);
-        if (a >= pr.ga[0] && a <= pr.ga[1] && b >= pr.ga[2] && b <= pr.gb[0]) { t_out = t; return true; }
-    }
-    return false;
+    float a = get(o, aA) + t * get(d, aA);
+    float b = get(o, bA) + t * get(d, bA);
+    t_out = t;
+    return (t <= t_max) & (t >= t_min) & (a >= pr.ga[0]) & (a <= pr.ga[1]) & (b >= pr.ga[2]) & (b <= pr.gb[0]);
 }
 
 // The HitRecord of an accepted intersection (Hitables.cpp:35-39,102-109, then the instance chain
