@@ -278,7 +278,10 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
 //    never NaN, and a NaN t0/t1 (0 * inf) is ignored by both forms;
 //  * t_min only grows and t_max only shrinks from axis to axis, so AABB.cpp:17's per-axis "t_max <= t_min -> miss"
 //    fires on some axis exactly when it fires on the final values: one compare instead of three early returns.
-__device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, float &t_near)
+// LEAF: the child is an object, which the reference never box-tests (SimpleObjectBVHNode::Hit tests its own box, then
+// calls Object::Hit): its box may only cull what the primitives inside cannot hit, so a grazing interval
+// (t_max == t_min: a ray through a box edge or corner, where a primitive can lie) passes.
+__device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, int32_t child, float &t_near)
 {
 #pragma unroll
     for (uint32_t a = 0; a < 3; ++a) {
@@ -291,7 +294,10 @@ __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f
         t_max = __builtin_fminf(tf, t_max);
     }
     t_near = t_min;
-    return !(t_max <= t_min);
+    // child < 0 (an object): "t_max < t_min -> miss", written as the node rule on the next float above t_max (t_max > 0
+    // whenever the answer can be "hit"; +inf steps to NaN, which the negated compare passes)
+    const float t_top = __uint_as_float(__float_as_uint(t_max) + ((uint32_t)child >> 31));
+    return !(t_top <= t_min);
 }
 
 template <bool PLDS>
@@ -314,8 +320,8 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                 n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
             }
             float tl = 0.0f, tr = 0.0f;
-            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, tl);
-            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, tr);
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, n.left, tl);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, n.right, tr);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 const int32_t far = left_first ? n.right : n.left;

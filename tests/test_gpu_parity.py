@@ -224,6 +224,39 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     H.assert_hits_equal(g1, o1, "own tree, reference order", uv_tol=2e-6)
 
 
+@pytest.mark.parametrize("world", ["cornell", "spheres4", "spheres"])
+def test_axis_parallel_rays(gpu, orc, world):
+    """Rays with zero direction components (1/d = inf, 0 * inf = NaN inside the slab tests) from origins on lattice
+    points, many of them on the planes of rects and of node boxes: the list walk, the reference-order walk and the
+    near-first walk (fmax/fmin slab test, one final compare) must all agree with the oracle."""
+    mk, w, h = WORLDS[world]
+    s, cam = mk()
+    s.nodes = None
+    capi.build_bvh(s)                                              # the library's own tree, for oracle and device alike
+    gpu.upload_scene(s)
+    rng = np.random.default_rng(77)
+    n = 16384
+    lat = 0.5 if world == "cornell" else 1.0
+    org = (rng.integers(-6, 7, (n, 3)) * lat).astype(np.float32)
+    d = rng.integers(-1, 2, (n, 3)).astype(np.float32)
+    d[(d == 0).all(axis=1)] = (0.0, -1.0, 0.0)
+    mix = rng.random(n) < 0.3                                      # some with one free component
+    d[mix, rng.integers(0, 3, mix.sum())] = rng.standard_normal(mix.sum()).astype(np.float32)
+    d[::7] = np.where(d[::7] == 0, np.float32(-0.0), d[::7])       # both signs of zero
+    o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
+    assert (o["prim"] >= 0).sum() > 500
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list", uv_tol=2e-6)
+    # the reference's BVH walk culls a ray that only grazes a node box (AABB.cpp:17 uses <=), so it misses some
+    # edge and corner hits the list finds; the device does the same in the same cases
+    o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order", uv_tol=2e-6)
+    # near-first: same node boxes under the same rule (objects themselves are not box-culled on a graze, as in the
+    # reference), so the same closest t; only the winner of an exact tie may differ
+    g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
+    H.assert_bits(g["t"], o1["t"], "axis-parallel near-first t")
+    assert np.array_equal(g["prim"] >= 0, o1["prim"] >= 0)
+
+
 def test_million_spheres(gpu, orc):
     """BASELINE config 4 (the generator of World.cpp:36-58 extended to a 1000x1000 grid, ~1M spheres): the host-built
     SAH tree is walked in the reference's order by the oracle and by the device (bit-exact hits and image), and
