@@ -225,54 +225,6 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     return best;
 }
 
-// BVH: SimpleObjectBVHNode::Hit (SimpleObject.cpp:389-406) as an explicit depth-first walk in the
-// recursion's order: box test with the *current* t_max when the node is reached (AABB.cpp:5-21),
-// left subtree completely, then right.  The pending right children live on a per-lane stack in
-// LDS ([level][lane] so a level is one conflict-free row); nodes with index < lds_nodes (the top
-// levels, nodes are numbered breadth-first at upload) are read from LDS, deeper ones from HBM as
-// one 32-byte record per lane.
-template <bool PLDS>
-__device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
-                                               float t_min, float &t_max)
-{
-    int32_t best = -1;
-    Stack stk(sc, v);
-    int32_t cur = sc.root;
-    const PrimRec *P = PLDS ? v.prims : sc.prims;
-    for (;;) {
-        if (cur >= 0) {
-            NodeRec n;
-            if ((uint32_t)cur < sc.lds_nodes) n = ((const NodeRec *)v.nodes)[cur];
-            else {
-                const float4 *g = (const float4 *)(sc.nodes + cur);
-                float4 a = g[0], b = g[1];
-                n.mn[0] = a.x; n.mn[1] = a.y; n.mn[2] = a.z; n.left = __float_as_int(a.w);
-                n.mx[0] = b.x; n.mx[1] = b.y; n.mx[2] = b.z; n.right = __float_as_int(b.w);
-            }
-            if (aabb_hit(n.mn, n.mx, o, d, t_min, t_max)) {
-                if (n.right != MIRT_CHILD_NONE) stk.push(n.right);
-                cur = n.left;
-                continue;
-            }
-        } else if (cur != MIRT_CHILD_NONE) {
-            uint2 ob = sc.objs[~cur];                       // Object::Hit, SimpleObject.cpp:73-83
-            for (uint32_t i = 0; i < ob.y; ++i) {
-                float t;
-                uint32_t p = ob.x + i;
-                if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
-            }
-        }
-        if (stk.sp == 0) break;
-        cur = stk.pop();
-    }
-    return best;
-}
-
-// Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
-// with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
-// current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
-// shrinks early and most of the far subtrees are culled by their box.  The closest t is the same as with
-// the reference's left-first order; only the winner of an exact tie in t can differ.
 // AABB::Hit's arithmetic with its control flow folded away, result unchanged:
 //  * (t0 > t_min) ? t0 : t_min is fmaxf(t0, t_min) and (t1 < t_max) ? t1 : t_max is fminf(t1, t_max): t_min/t_max are
 //    never NaN, and a NaN t0/t1 (0 * inf) is ignored by both forms;
@@ -300,6 +252,56 @@ __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f
     return !(t_top <= t_min);
 }
 
+// BVH: SimpleObjectBVHNode::Hit (SimpleObject.cpp:389-406) as an explicit depth-first walk in the
+// recursion's order: box test with the *current* t_max when the node is reached (AABB.cpp:5-21),
+// left subtree completely, then right.  The pending right children live on a per-lane stack in
+// LDS ([level][lane] so a level is one conflict-free row); nodes with index < lds_nodes (the top
+// levels, nodes are numbered breadth-first at upload) are read from LDS, deeper ones from HBM as
+// one 32-byte record per lane.
+template <bool PLDS>
+__device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
+                                               float t_min, float &t_max)
+{
+    int32_t best = -1;
+    Stack stk(sc, v);
+    int32_t cur = sc.root;
+    const PrimRec *P = PLDS ? v.prims : sc.prims;
+    const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
+    for (;;) {
+        if (cur >= 0) {
+            NodeRec n;
+            if ((uint32_t)cur < sc.lds_nodes) n = ((const NodeRec *)v.nodes)[cur];
+            else {
+                const float4 *g = (const float4 *)(sc.nodes + cur);
+                float4 a = g[0], b = g[1];
+                n.mn[0] = a.x; n.mn[1] = a.y; n.mn[2] = a.z; n.left = __float_as_int(a.w);
+                n.mx[0] = b.x; n.mx[1] = b.y; n.mx[2] = b.z; n.right = __float_as_int(b.w);
+            }
+            float t_in;
+            if (slab_hit(n.mn, n.mx, o, invd, t_min, t_max, 0, t_in)) {   // AABB::Hit on this node's own box (never an object's)
+                if (n.right != MIRT_CHILD_NONE) stk.push(n.right);
+                cur = n.left;
+                continue;
+            }
+        } else if (cur != MIRT_CHILD_NONE) {
+            uint2 ob = sc.objs[~cur];                       // Object::Hit, SimpleObject.cpp:73-83
+            for (uint32_t i = 0; i < ob.y; ++i) {
+                float t;
+                uint32_t p = ob.x + i;
+                if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+            }
+        }
+        if (stk.sp == 0) break;
+        cur = stk.pop();
+    }
+    return best;
+}
+
+// Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
+// with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
+// current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
+// shrinks early and most of the far subtrees are culled by their box.  The closest t is the same as with
+// the reference's left-first order; only the winner of an exact tie in t can differ.
 template <bool PLDS>
 __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max)
 {
