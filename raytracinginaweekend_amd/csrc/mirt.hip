@@ -38,7 +38,8 @@ struct mirt_ctx {
     SceneDev sc{};                  // LDS plan for the list / reference-order walk (32-byte nodes)
     SceneDev sc2{};                 // LDS plan for the near-first walk (64-byte nodes)
     uint32_t lds_bytes = 0, lds_bytes2 = 0, lds_stack_bytes = 0;   // the stack comes last in the plan: the list walk launches without it
-    bool prims_in_lds = false;
+    bool prims_in_lds = false;      // primitive AND material tables staged in LDS: the PLDS kernel variants
+    bool small_scene = false;       // the primitive table is small enough for the list walk (ACCEL_AUTO)
     mirt_camera cam{};
     DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
@@ -247,7 +248,8 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.spill = nullptr; d.spill_stride = 0;
     uint32_t used = d.stack_lds * MIRT_BLOCK * 4u;
     d.lds_mats = (s->n_mats * sizeof(MatRec) <= c->lds_mats) ? s->n_mats : 0u; used += d.lds_mats * (uint32_t)sizeof(MatRec);
-    c->prims_in_lds = (size_t)s->n_prims * sizeof(PrimRec) <= c->lds_prims && d.lds_mats == s->n_mats;       // scenes the list walk is meant for; larger ones keep the LDS for residency
+    c->small_scene = (size_t)s->n_prims * sizeof(PrimRec) <= c->lds_prims;       // scenes the list walk is meant for; larger ones keep the LDS for residency
+    c->prims_in_lds = c->small_scene && d.lds_mats == s->n_mats;                 // a long material table (it need not be used) leaves both in HBM
     d.lds_prims = c->prims_in_lds ? s->n_prims : 0u; used += d.lds_prims * (uint32_t)sizeof(PrimRec);
     const uint32_t room_bytes = used < budget ? budget - used : 0u;
     c->sc2 = d;
@@ -294,7 +296,7 @@ extern "C" int mirt_set_camera(mirt_ctx *c, const mirt_camera *cam)
 static int accel_mode(const mirt_ctx *c, uint32_t flags)
 {
     if (flags & MIRT_FLAG_ACCEL_LIST) return 0;
-    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 48 && c->prims_in_lds) ? 0 : 2;
+    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 48 && c->small_scene) ? 0 : 2;
     if (flags & MIRT_FLAG_ACCEL_ORDERED) return 2;
     return 1;
 }

@@ -7,11 +7,15 @@ from raytracinginaweekend_amd import capi, scene
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 world = sys.argv[2] if len(sys.argv) > 2 else "cornell"
 w, h = (1024, 1024) if world == "cornell" else (1200, 800)
+if os.environ.get("MIRT_SIZE"):
+    w, h = (int(x) for x in os.environ["MIRT_SIZE"].split("x"))
 if world == "cornell":
     s, cam = scene.cornell_box(1.0)
 elif world == "textured":                     # two 1024^2 image textures (4 MB each) on floor, wall and ball
     from tests import helpers as H
     s, cam = scene.textured_world(w / h, H.synthetic_texture(1024, 1024, 1, "ramp"), H.synthetic_texture(1024, 1024, 2, "checker"))
+elif world == "spheres4":                     # BASELINE config 0: ground + three big spheres
+    s, cam = scene.spheres_world(w / h, small_spheres=False)
 elif world == "spheres1m":                    # BASELINE config 4: ~1M spheres, camera raised to see the field
     s, cam = scene.spheres_world(w / h, grid=500, look_from=(26.0, 6.0, 6.0))
 else:
