@@ -188,11 +188,21 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
 
     const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (unrotated spheres)
     float p_b = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;                  // the parked sphere: b, discriminant, index (-1: none)
+    // Which root survives (the first unless it is below t_min, Hitables.cpp:31-41) is decided by an estimate of the
+    // first quotient wherever that is safe -- the estimate is within 3e-7 of the quotient, the band around t_min is
+    // 1e-5 wide -- so one IEEE divide runs instead of two; inside the band (or with a NaN) both run as written.
+    const float inv2a = __builtin_amdgcn_rcpf(two_a), t_lo = t_min * 0.99999f, t_hi = t_min * 1.00001f;
     auto resolve = [&]() {
         if (p_idx >= 0) {
             const float sq = __builtin_sqrtf(p_disc);
-            float t = (-p_b - sq) / two_a;                               // Hitables.cpp:31
-            if (!(t >= t_min)) t = (-p_b + sq) / two_a;                  // :41
+            const float n1 = -p_b - sq, n2 = -p_b + sq;
+            const float q1 = n1 * inv2a;
+            const bool first = q1 > t_hi, second = q1 < t_lo;
+            float t = (first ? n1 : n2) / two_a;
+            if (!(first | second)) {
+                t = n1 / two_a;                                          // Hitables.cpp:31
+                if (!(t >= t_min)) t = n2 / two_a;                       // :41
+            }
             if ((t >= t_min) & ((t < t_max) | ((t == t_max) & (p_idx > best)))) { t_max = t; best = p_idx; }
             p_idx = -1;
         }
