@@ -32,9 +32,12 @@ __device__ __forceinline__ f3 normalize(f3 a)                                   
 {
     float l2 = dot(a, a);
     float l = __builtin_sqrtf(l2);
-    if (l == 0.0f) return mk(0.0f, 0.0f, 0.0f);
-    if (__builtin_isinf(l2)) { float q = __builtin_nanf(""); return mk(q, q, q); }
-    return mk(a.x / l, a.y / l, a.z / l);
+    f3 r = mk(a.x / l, a.y / l, a.z / l);
+    if ((l == 0.0f) | __builtin_isinf(l2)) {                  // both special cases behind one, almost never taken, branch
+        const float q = (l == 0.0f) ? 0.0f : __builtin_nanf("");
+        r = mk(q, q, q);
+    }
+    return r;
 }
 __device__ __forceinline__ f3 ray_at(f3 o, f3 d, float t) { return o + scale(d, t); }                 // Ray.h:14
 

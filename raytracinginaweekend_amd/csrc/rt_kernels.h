@@ -141,19 +141,20 @@ __device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
 //    Which root is taken does not depend on t_max (the second root is never smaller than the first), and a
 //    parked sphere is accepted under the sequential rule "t <= t_max, later index wins a tie" restated with
 //    the index: t < t_max || (t == t_max && index > best).
+typedef uint32_t ListWord4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) ListWord4 *ListPtr;   // records of the sorted list, read through the scalar cache
 // One class of the sorted list: unrotated rects whose axis triple is (A, B, C).  Branch-free on purpose: with 64
 // unrelated rays some lane always passes the t test, so skipping a/b buys nothing and the selects keep the loop
 // free of phi copies.  pr.mat of the sorted copy holds the primitive's index in the scene's own order.
 template <int A, int B, int C>
-__device__ __forceinline__ void rect_run(const SceneDev &sc, uint32_t &p, uint32_t end, f3 o, f3 d,
+__device__ __forceinline__ void rect_run(ListPtr &q, uint32_t &p, uint32_t end, f3 o, f3 d,
                                          float t_min, float &t_max, int32_t &best)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const float dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
     const float da = A == 0 ? d.x : (A == 1 ? d.y : d.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
-    for (; p < end; ++p) {
-        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
+    for (; p < end; ++p, q += 4) {                                          // one running record pointer through all the class loops
         const u32x4 q0 = q[0], q1 = q[1];
         const u32x2 q2 = *(const __attribute__((address_space(4))) u32x2 *)(q + 2);
         const f3 ol = o - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
@@ -182,9 +183,10 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     int32_t best = -1;
     uint32_t p = 0;
-    rect_run<0, 1, 2>(sc, p, sc.lend[0], o, d, t_min, t_max, best);
-    rect_run<0, 2, 1>(sc, p, sc.lend[1], o, d, t_min, t_max, best);
-    rect_run<2, 1, 0>(sc, p, sc.lend[2], o, d, t_min, t_max, best);
+    ListPtr q = (ListPtr)sc.lprims;
+    rect_run<0, 1, 2>(q, p, sc.lend[0], o, d, t_min, t_max, best);
+    rect_run<0, 2, 1>(q, p, sc.lend[1], o, d, t_min, t_max, best);
+    rect_run<2, 1, 0>(q, p, sc.lend[2], o, d, t_min, t_max, best);
 
     const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (unrotated spheres)
     float p_b = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;                  // the parked sphere: b, discriminant, index (-1: none)
@@ -207,8 +209,7 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
             p_idx = -1;
         }
     };
-    for (; p < sc.lend[3]; ++p) {
-        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
+    for (; p < sc.lend[3]; ++p, q += 4) {
         const u32x4 q0 = q[0], q1 = q[1];
         const f3 oc = o - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         const float b = 2.0f * dot(d, oc);
@@ -219,10 +220,9 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         if (cross) { p_b = b; p_disc = disc; p_idx = (int32_t)q1.w; }
     }
     resolve();
-    for (; p < sc.n_prims; ++p) {
+    for (; p < sc.n_prims; ++p, q += 4) {
         // every lane walks the same primitive: the record comes through the scalar cache straight into SGPRs (s_load;
         // the scene is read-only for the whole launch, so the constant address space is legitimate).
-        const __attribute__((address_space(4))) u32x4 *q = (const __attribute__((address_space(4))) u32x4 *)(sc.lprims + p);
         const u32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
         PrimRec pr;
         pr.off[0] = __uint_as_float(q0.x); pr.off[1] = __uint_as_float(q0.y); pr.off[2] = __uint_as_float(q0.z); pr.info = q0.w;
