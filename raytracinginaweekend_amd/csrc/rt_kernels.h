@@ -132,15 +132,16 @@ __device__ __forceinline__ void lds_stage(const SceneDev &sc, const LdsView &v)
 // ---------------------------------------------------------------------------------- closest hit
 // List: Hitables.cpp:130-142 semantics over every object in order (= every primitive in order):
 // t_max shrinks on each accepted hit, `<=` lets a later primitive win a tie.  All lanes walk the
-// same primitive, so the records are wave-uniform LDS broadcasts.
-// Two things are done differently from a literal walk, neither changes a bit of the result:
-//  * rect tests are specialised on the (wave-uniform) axis triple, so components are picked at compile time;
-//  * a sphere's roots (IEEE sqrt + one or two IEEE divides, ~50 instructions that only the few lanes whose
-//    line meets the sphere need) are deferred: the lane parks (-b, disc, index) and the roots are evaluated
-//    once after the loop -- or earlier, when a lane that already has a parked sphere meets another one.
-//    Which root is taken does not depend on t_max (the second root is never smaller than the first), and a
-//    parked sphere is accepted under the sequential rule "t <= t_max, later index wins a tie" restated with
-//    the index: t < t_max || (t == t_max && index > best).
+// same primitive, so a record is wave-uniform: it comes through the scalar cache into SGPRs.
+// Three things are done differently from a literal walk, none changes a bit of the result:
+//  * the walk goes over a copy sorted by class, one loop per class (see closest_list below), with the reference's
+//    sequential rule "t <= t_max, later index wins a tie" restated with the scene index so that order does not
+//    matter: t < t_max || (t == t_max && index > best);
+//  * rect tests have their axis triple fixed at compile time and no early-outs;
+//  * a sphere's roots (IEEE sqrt + IEEE divide, ~45 instructions that only the few lanes whose line meets the
+//    sphere need) are deferred: the lane parks (b, disc, index) and the roots are evaluated once after the
+//    loop -- or earlier, when a lane that already has a parked sphere meets another one.  Which root is taken
+//    does not depend on t_max (the second root is never smaller than the first).
 typedef uint32_t ListWord4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) ListWord4 *ListPtr;   // records of the sorted list, read through the scalar cache
 // One class of the sorted list: unrotated rects whose axis triple is (A, B, C).  Branch-free on purpose: with 64
