@@ -217,7 +217,10 @@ int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32
 
 /* Arithmetic self-test of the device's IEEE building blocks (no reference counterpart; parity
  * tests bind it): op 0 x/y, 1 sqrt(x), 2 x^5 as Schlick evaluates it (Optics.h:31), 3 the [0,1)
- * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x. */
+ * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x, 5 x/y as the
+ * rect test computes it (the division sequence with the denominator-only part shared between
+ * the rects of one orientation, falling back to x/y outside its operand range), 6 whether op 5
+ * used the shared sequence (1.0) or fell back (0.0).  y is required for ops 0, 5 and 6. */
 int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
 /* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: uv = n (u,v) pairs -> n RGB triples of texture `tex` */
 int mirt_tex_sample_batch(mirt_ctx *ctx, uint32_t tex, const float *uv, size_t n, float *rgb_out);

@@ -233,6 +233,11 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     }
     d.prims = (const PrimRec *)c->d_prims.p; d.n_prims = s->n_prims;
     d.lprims = (const PrimRec *)c->d_lprims.p; for (int i = 0; i < 4; ++i) d.lend[i] = lend[i];
+    d.list_fast = 1u;
+    for (uint32_t i = 0; i < lend[2]; ++i) {
+        const PrimRec &r = lprims[i];
+        if (!(std::fabs(r.gb[1]) <= 0x1p38f && std::fabs(r.off[0]) <= 0x1p38f && std::fabs(r.off[1]) <= 0x1p38f && std::fabs(r.off[2]) <= 0x1p38f)) d.list_fast = 0u;
+    }
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;
@@ -783,7 +788,7 @@ extern "C" int mirt_tex_sample_batch(mirt_ctx *c, uint32_t tex, const float *uv,
 
 extern "C" int mirt_arith_batch(mirt_ctx *c, uint32_t op, const float *x, const float *y, size_t n, float *out)
 {
-    if (!c || !x || !out || op > 4) return MIRT_ERR_ARG;
+    if (!c || !x || !out || op > 6 || ((op == 0 || op >= 5) && !y)) return MIRT_ERR_ARG;
     if (!n) return MIRT_OK;
     CHECK_N(n);
     HIPCHK(c, hipSetDevice(c->device));

@@ -41,6 +41,32 @@ __device__ __forceinline__ f3 normalize(f3 a)                                   
 }
 __device__ __forceinline__ f3 ray_at(f3 o, f3 d, float t) { return o + scale(d, t); }                 // Ray.h:14
 
+// ----------------------------------------------------------------------------- many IEEE quotients, one denominator
+// x / den for several x (the rects of one orientation all divide by the same ray-direction component).  This is the
+// hardware's own f32 division sequence (v_div_scale x2, v_rcp, 2 fma on the reciprocal, mul, 3 fma, v_div_fmas,
+// v_div_fixup) with the part that depends on the denominator alone hoisted out: when neither operand needs
+// v_div_scale's rescaling the scaled operands are the operands themselves, v_div_fmas is a plain fma and v_div_fixup
+// passes its input through, so the five remaining operations give the very bits of `x / den`.
+// Promise (tests/test_gpu_parity.py::test_shared_denominator_division checks it against `/` on 2^26 pairs and the
+// edges): for |den| in [2^-20, 2^20] and |x| in [2^-40, 2^40] or x == +0 the result is x / den bit for bit; for
+// smaller |x| (and x == -0) it is only guaranteed to stay below 2^-19 in magnitude, like the true quotient.
+struct DivBy { float den, r1; };
+__device__ __forceinline__ DivBy div_prepare(float den)
+{
+    DivBy q; q.den = den;
+    const float r0 = __builtin_amdgcn_rcpf(den);
+    q.r1 = __builtin_fmaf(__builtin_fmaf(-den, r0, 1.0f), r0, r0);
+    return q;
+}
+__device__ __forceinline__ bool div_den_ok(float den) { const float ad = __builtin_fabsf(den); return (ad >= 0x1p-20f) & (ad <= 0x1p20f); }
+__device__ __forceinline__ bool div_num_ok(float x) { const float ax = __builtin_fabsf(x); return ((ax >= 0x1p-40f) & (ax <= 0x1p40f)) | (__float_as_uint(x) == 0u); }
+__device__ __forceinline__ float div_by(const DivBy &q, float x)
+{
+    const float q0 = x * q.r1;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-q.den, q0, x), q.r1, q0);
+    return __builtin_fmaf(__builtin_fmaf(-q.den, q1, x), q.r1, q1);
+}
+
 // ----------------------------------------------------------------------------- RNG source
 // Philox4x32-10 (Salmon et al. SC'11) replaces std::random_device (Randomizer.h:11,22).
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,

@@ -36,6 +36,7 @@ struct PathQ {
 struct SceneDev {
     const PrimRec *prims;  uint32_t n_prims;
     const PrimRec *lprims; uint32_t lend[4];     // the list walk's copy, sorted by class (closest_list); .mat = index in `prims`
+    uint32_t list_fast;                           // every unrotated rect has |plane|, |offset| <= 2^38: rect_run may share its divisions
     const NodeRec *nodes;  uint32_t n_nodes;     // the tree as given (or built), walked in the reference's order
     const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
     uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
@@ -147,14 +148,20 @@ typedef const __attribute__((address_space(4))) ListWord4 *ListPtr;   // records
 // One class of the sorted list: unrotated rects whose axis triple is (A, B, C).  Branch-free on purpose: with 64
 // unrelated rays some lane always passes the t test, so skipping a/b buys nothing and the selects keep the loop
 // free of phi copies.  pr.mat of the sorted copy holds the primitive's index in the scene's own order.
-template <int A, int B, int C>
-__device__ __forceinline__ void rect_run(ListPtr &q, uint32_t &p, uint32_t end, f3 o, f3 d,
-                                         float t_min, float &t_max, int32_t &best)
+// FAST: t = (k - origin.c) / direction.c through div_by (rt_device.h), five operations instead of the twelve of a full
+// IEEE divide because every rect of the class divides by the same direction.c.  closest_list takes it when the whole wave
+// is inside div_by's operand range (see there); a numerator too small for its promise gives |t| < 2^-19 <= t_min
+// either way, so the rect is missed by both forms.
+template <int A, int B, int C, bool FAST>
+__device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end, f3 o, f3 d,
+                                          float t_min, float &t_max, int32_t &best)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     const float dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
     const float da = A == 0 ? d.x : (A == 1 ? d.y : d.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
+    if (p >= end) return;
+    const DivBy by_dc = div_prepare(dc);
     for (; p < end; ++p, q += 4) {                                          // one running record pointer through all the class loops
         const u32x4 q0 = q[0], q1 = q[1];
         const u32x2 q2 = *(const __attribute__((address_space(4))) u32x2 *)(q + 2);
@@ -162,7 +169,8 @@ __device__ __forceinline__ void rect_run(ListPtr &q, uint32_t &p, uint32_t end, 
         const int32_t idx = (int32_t)q1.w;
         const float oc = C == 0 ? ol.x : (C == 1 ? ol.y : ol.z);
         const float oa = A == 0 ? ol.x : (A == 1 ? ol.y : ol.z), ob = B == 0 ? ol.x : (B == 1 ? ol.y : ol.z);
-        const float t = (__uint_as_float(q2.y) - oc) / dc;                 // Hitables.cpp:95
+        const float num = __uint_as_float(q2.y) - oc;
+        const float t = FAST ? div_by(by_dc, num) : num / dc;               // Hitables.cpp:95
         const float a = oa + t * da;
         const float b = ob + t * db;
         const bool in_t = (t >= t_min) & ((t < t_max) | ((t == t_max) & (idx > best)));
@@ -172,7 +180,6 @@ __device__ __forceinline__ void rect_run(ListPtr &q, uint32_t &p, uint32_t end, 
         best = hit ? idx : best;
     }
 }
-
 // The list is walked in class order (mirt.hip sorts a copy at upload: the three unrotated rect orientations, unrotated
 // spheres, everything else), each class by its own loop with the axes fixed at compile time and nothing to classify
 // per primitive.  Walking out of order is safe because acceptance carries the scene index:
@@ -185,9 +192,24 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     int32_t best = -1;
     uint32_t p = 0;
     ListPtr q = (ListPtr)sc.lprims;
-    rect_run<0, 1, 2>(q, p, sc.lend[0], o, d, t_min, t_max, best);
-    rect_run<0, 2, 1>(q, p, sc.lend[1], o, d, t_min, t_max, best);
-    rect_run<2, 1, 0>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+    if (sc.lend[2] != 0u) {
+        // May the rect loops share their divisions (rect_loop<FAST>, div_by)?  Every lane's three direction components in
+        // [2^-20, 2^20] and |k - (origin.c - offset.c)| <= 2^40: the upload vouches for |k|, |offset| <= 2^38 (list_fast), the
+        // lane for its origin.  A NaN component passes the max3/min3 tests, harmlessly: both forms then give t = NaN.
+        const float d_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+        const float d_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
+        const float o_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
+        const bool fast = (sc.list_fast != 0u) & (t_min >= 0x1p-19f) & (d_hi <= 0x1p20f) & (d_lo >= 0x1p-20f) & (o_hi <= 0x1p38f);
+        if (__ballot(!fast) == 0ull) {
+            rect_loop<0, 1, 2, true>(q, p, sc.lend[0], o, d, t_min, t_max, best);
+            rect_loop<0, 2, 1, true>(q, p, sc.lend[1], o, d, t_min, t_max, best);
+            rect_loop<2, 1, 0, true>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+        } else {
+            rect_loop<0, 1, 2, false>(q, p, sc.lend[0], o, d, t_min, t_max, best);
+            rect_loop<0, 2, 1, false>(q, p, sc.lend[1], o, d, t_min, t_max, best);
+            rect_loop<2, 1, 0, false>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+        }
+    }
 
     const float a_dd = dot(d, d), two_a = 2.0f * a_dd, four_a = 4 * a_dd;   // Hitables.cpp:22,26,31 (unrotated spheres)
     float p_b = 0.0f, p_disc = 0.0f; int32_t p_idx = -1;                  // the parked sphere: b, discriminant, index (-1: none)
@@ -215,8 +237,13 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         const f3 oc = o - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
         const float b = 2.0f * dot(d, oc);
         const float c = dot(oc, oc) - __uint_as_float(q1.z);
-        const float disc = b * b - four_a * c;
-        const bool cross = disc > 0;
+        const float bb = b * b;
+        const float disc = bb - four_a * c;
+        // A sphere wholly behind the origin (b > 0, c > 0) has two non-positive roots and is not parked.  disc < bb
+        // makes that exact in float arithmetic: sqrt rounds monotonically, so sqrt(disc) <= b and -b + sqrt(disc) <= 0;
+        // when four_a * c was absorbed (disc == bb) the sphere is parked and judged by its roots as written.
+        const bool behind = (b > 0.0f) & (c > 0.0f) & (disc < bb);
+        const bool cross = (disc > 0) & !behind;
         if (__ballot(cross & (p_idx >= 0)) != 0ull) resolve();
         if (cross) { p_b = b; p_disc = disc; p_idx = (int32_t)q1.w; }
     }
@@ -960,7 +987,8 @@ __global__ void k_philox_batch(const uint32_t *ctr, uint32_t n, uint32_t k0, uin
     out[4 * i] = r[0]; out[4 * i + 1] = r[1]; out[4 * i + 2] = r[2]; out[4 * i + 3] = r[3];
 }
 
-// arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a)
+// arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a),
+// 5 div_by(div_prepare(b), a), 6 whether (a, b) lies where 5 promises the bits of a / b
 __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n, float *out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -971,7 +999,9 @@ __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n,
     case 1: r = __builtin_sqrtf(a); break;
     case 2: r = pow5f(a); break;
     case 3: r = map_unorm(__float_as_uint(a)); break;
-    default: r = map_pm1(__float_as_uint(a)); break;
+    case 4: r = map_pm1(__float_as_uint(a)); break;
+    case 5: r = div_by(div_prepare(b), a); break;                        // the shared-denominator division of rect_run, raw
+    default: r = (div_den_ok(b) & div_num_ok(a)) ? 1.0f : 0.0f; break;     // 6: inside the operand range where 5 promises the bits of a / b
     }
     out[i] = r;
 }

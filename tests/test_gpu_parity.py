@@ -33,6 +33,36 @@ def test_arith_blocks(gpu, orc):
     H.assert_bits(gpu.arith_batch(4, raw.view(np.float32)), ((d / 4294967295.0) * 2.0 + -1.0).astype(np.float32), "map_pm1/all")
 
 
+def test_shared_denominator_division(gpu):
+    """div_prepare/div_by (rt_device.h: the hardware division sequence with the denominator-only part hoisted) must
+    give the bits of `/` wherever it promises them (|den| in [2^-20, 2^20], |x| in [2^-40, 2^40] or x == +0): 2^26
+    random pairs reaching a little beyond that range, and the range limits.  Below the numerator range it only
+    promises a quotient under 2^-19 in magnitude."""
+    rng = np.random.default_rng(2024)
+    n = 1 << 22
+    for rep in range(16):
+        mant = rng.integers(0, 1 << 23, (2, n), dtype=np.uint32)
+        sign = rng.integers(0, 2, (2, n), dtype=np.uint32) << 31
+        ex = rng.integers(127 - 44, 127 + 43, n, dtype=np.uint32)                # numerators a little beyond [2^-40, 2^40]
+        ey = rng.integers(127 - 22, 127 + 23, n, dtype=np.uint32)                # denominators a little beyond [2^-20, 2^20]
+        x = (sign[0] | (ex << 23) | mant[0]).view(np.float32)
+        y = (sign[1] | (ey << 23) | mant[1]).view(np.float32)
+        if rep == 0:
+            x[:4096] = 0.0
+            y[:1024] = np.float32(3.0); x[8192:12288] = np.linspace(-2, 2, 4096, dtype=np.float32)
+            x[12288:12800] = np.float32(2.0 ** -40); x[12800:13312] = np.float32(2.0 ** 40)
+            y[13312:13824] = np.float32(2.0 ** -20); y[13824:14336] = np.float32(-2.0 ** 20)
+        with np.errstate(all="ignore"):
+            want = (x / y).astype(np.float32)
+        got = gpu.arith_batch(5, x, y)
+        inside = gpu.arith_batch(6, x, y) == 1.0
+        ref_inside = (((np.abs(x) >= 2.0 ** -40) & (np.abs(x) <= 2.0 ** 40)) | (x.view(np.uint32) == 0)) & (np.abs(y) >= 2.0 ** -20) & (np.abs(y) <= 2.0 ** 20)
+        assert np.array_equal(inside, ref_inside) and inside.mean() > 0.8
+        assert np.array_equal(got.view(np.uint32)[inside], want.view(np.uint32)[inside]), f"block {rep}"     # the sign of a zero included
+        small = (np.abs(x) < 2.0 ** -40) & (np.abs(y) >= 2.0 ** -20) & (np.abs(y) <= 2.0 ** 20)
+        assert small.any() and (np.abs(got[small]) < 2.0 ** -19).all()
+
+
 def test_philox(gpu, orc):
     rng = np.random.default_rng(2)
     ctr = rng.integers(0, 2 ** 32, (512, 4), dtype=np.uint64).astype(np.uint32)
