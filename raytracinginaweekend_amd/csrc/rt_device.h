@@ -28,19 +28,6 @@ __device__ __forceinline__ f3 neg(f3 a) { return mk(0.0f - a.x, 0.0f - a.y, 0.0f
 __device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }      // Vec3.h:90-93
 __device__ __forceinline__ float get(f3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 __device__ __forceinline__ void set(f3 &a, uint32_t i, float f) { if (i == 0) a.x = f; else if (i == 1) a.y = f; else a.z = f; }
-__device__ __forceinline__ f3 normalize(f3 a)                                                         // Vec3.h:100-103
-{
-    float l2 = dot(a, a);
-    float l = __builtin_sqrtf(l2);
-    f3 r = mk(a.x / l, a.y / l, a.z / l);
-    if ((l == 0.0f) | __builtin_isinf(l2)) {                  // both special cases behind one, almost never taken, branch
-        const float q = (l == 0.0f) ? 0.0f : __builtin_nanf("");
-        r = mk(q, q, q);
-    }
-    return r;
-}
-__device__ __forceinline__ f3 ray_at(f3 o, f3 d, float t) { return o + scale(d, t); }                 // Ray.h:14
-
 // ----------------------------------------------------------------------------- many IEEE quotients, one denominator
 // x / den for several x (the rects of one orientation all divide by the same ray-direction component).  This is the
 // hardware's own f32 division sequence (v_div_scale x2, v_rcp, 2 fma on the reciprocal, mul, 3 fma, v_div_fmas,
@@ -66,6 +53,29 @@ __device__ __forceinline__ float div_by(const DivBy &q, float x)
     const float q1 = __builtin_fmaf(__builtin_fmaf(-q.den, q0, x), q.r1, q0);
     return __builtin_fmaf(__builtin_fmaf(-q.den, q1, x), q.r1, q1);
 }
+
+__device__ __forceinline__ f3 normalize(f3 a)                                                         // Vec3.h:100-103
+{
+    float l2 = dot(a, a);
+    float l = __builtin_sqrtf(l2);
+    // three quotients, one denominator: div_by when every active lane is inside its range -- all components in
+    // [2^-40, 2^19] in magnitude, the largest at least 2^-19, which puts l in [2^-20, 2^20]; exact zeros, NaN and
+    // out-of-range vectors take the plain divides, whole wave
+    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az), lo = __builtin_fminf(__builtin_fminf(ax, ay), az);
+    const bool fast = (lo >= 0x1p-40f) & (hi >= 0x1p-19f) & (hi <= 0x1p19f) & (ax == ax) & (ay == ay) & (az == az);
+    f3 r;
+    if (__ballot(!fast) == 0ull) {
+        const DivBy by_l = div_prepare(l);
+        r = mk(div_by(by_l, a.x), div_by(by_l, a.y), div_by(by_l, a.z));
+    } else r = mk(a.x / l, a.y / l, a.z / l);
+    if ((l == 0.0f) | __builtin_isinf(l2)) {                  // both special cases behind one, almost never taken, branch
+        const float q = (l == 0.0f) ? 0.0f : __builtin_nanf("");
+        r = mk(q, q, q);
+    }
+    return r;
+}
+__device__ __forceinline__ f3 ray_at(f3 o, f3 d, float t) { return o + scale(d, t); }                 // Ray.h:14
 
 // ----------------------------------------------------------------------------- RNG source
 // Philox4x32-10 (Salmon et al. SC'11) replaces std::random_device (Randomizer.h:11,22).
