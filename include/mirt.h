@@ -144,11 +144,15 @@ int         mirt_device_count(void);
  *  "engine"         1 (default): persistent kernel, one path per lane, no path queues;
  *                   0: wavefront formulation, one launch per bounce over compacted path queues.
  *                   Both produce the same bits.
+ *                   (engine 0: single-colour scenes only; batches of at most 256 Mi paths)
  *  "blocks_per_cu"  workgroups per CU of the persistent grid (0 = occupancy query, default)
- *                   0: wavefront formulation (single-colour scenes only; batches of at most 256 Mi paths)
- *  "lds_budget", "stack_lds", "lds_mats"  LDS plan of the next mirt_upload_scene: bytes per workgroup up to which
- *                   the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS (default 2,
- *                   the rest spills to HBM), largest material table staged (default 1024 bytes) */
+ *  "tile_paths"     1 (default): with a BVH walk, the persistent engine hands out pixels in 8x8 tiles rather than
+ *                   rows (compact patches of camera rays); 0: rows.  No effect on the image.
+ *  "lds_budget", "stack_lds", "lds_mats", "lds_prims"  LDS plan of the next mirt_upload_scene: bytes per workgroup
+ *                   up to which the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS
+ *                   (default 2, the rest spills to HBM), largest material table staged (default 1024 bytes),
+ *                   largest primitive table staged (default 4096 bytes; such scenes are walked as a list under
+ *                   MIRT_FLAG_ACCEL_AUTO when they have at most 48 primitives) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 
 /* -- scene ---------------------------------------------------------------------------------- */

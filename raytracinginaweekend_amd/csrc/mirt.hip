@@ -52,6 +52,7 @@ struct mirt_ctx {
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
+    uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
     uint32_t stack_lds = 2;                // traversal-stack levels kept in LDS (1 KiB each); likewise
     std::vector<hipEvent_t> ev_pool;
@@ -124,6 +125,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "lds_prims")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_prims out of range"); c->lds_prims = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -402,6 +404,8 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
+    // BVH walks gain ~2 % from compact 8x8 patches of camera rays; the list walk loses ~3 % (paths of one patch end together)
+    a.tiles_x = (c->tile_paths && mode != 0 && p->width % 8u == 0 && p->height % 8u == 0) ? p->width / 8u : 0u;
     uint32_t batch = 0;
     const bool timed = stats && c->time_launches;
     if (timed) while (c->ev_pool.size() < 2 * (size_t)n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
@@ -421,7 +425,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             launch_trace(c, mode, a, grid, st);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch + 1], st));
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
-                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u);
+                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u, a.tiles_x, a.width);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -543,7 +547,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
                 if (p->flags & MIRT_FLAG_NORMAL_DISPLAY) break;      // every path ends at its first vertex
             }
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
-                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u);
+                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u, 0u, p->width);
         }
     }
     HIPCHK(c, hipGetLastError());

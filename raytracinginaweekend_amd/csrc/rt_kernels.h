@@ -385,6 +385,18 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     return best;
 }
 
+// Path ids enumerate pixels tile by tile (8x8) rather than row by row, so the 64 camera rays a wave generates at
+// once cover a compact patch: their walks through a BVH stay together longer.  A bijection on the image (both sides
+// multiples of 8; tiles_x = 0 turns it off); the pixel it returns is the real one -- the Philox key, the camera ray,
+// the slot of the sum -- so no result depends on it.  k_accumulate applies the same map.
+__device__ __forceinline__ uint32_t tile_pixel(uint32_t g, uint32_t tiles_x, uint32_t width)
+{
+    if (tiles_x == 0u) return g;
+    const uint32_t tile = g >> 6, in = g & 63u;
+    const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    return (ty * 8u + (in >> 3)) * width + tx * 8u + (in & 7u);
+}
+
 // ---------------------------------------------------------------------------------- ray generation
 // HomemadeRayTracer.cpp:114-131 + SimpleCamera.cpp:55-60 + Randomizer.h:50-58
 template <class Args>
@@ -646,6 +658,7 @@ struct TraceArgs {
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
     uint32_t max_depth, flags, k0, k1;
+    uint32_t tiles_x;              // > 0: path ids run over 8x8 pixel tiles (tile_pixel), tiles_x = width / 8
 };
 // 128 entries: topped up whenever fewer than 64 remain, so one pass always serves every idle lane (list walk:
 // the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
@@ -711,7 +724,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const uint32_t id = w_next + lane;
                         const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
                         f3 go, gd;
-                        generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
+                        generate_ray(a, tile_pixel(a.pix0 + pl, a.tiles_x, a.width), a.spp0 + sl, go, gd);
                         const uint32_t e = cnt + lane;
                         stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
@@ -729,7 +742,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     const float4 qa = stash.a[e], qb = stash.b[e];
                     o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                     const uint32_t sl = __float_as_uint(qb.w);
-                    sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
+                    sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
                     thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                 }
                 const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -751,7 +764,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const float4 qa = stash.a[e], qb = stash.b[e];
                         o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                         const uint32_t sl = __float_as_uint(qb.w);
-                        sample = a.spp0 + sl; pixel = a.pix0 + (pid - sl * a.npix);
+                        sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
                         thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                     }
                     cnt -= take; served += take;
@@ -769,7 +782,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const uint32_t id = w_next + lane;
                         const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
                         f3 go, gd;
-                        generate_ray(a, a.pix0 + pl, a.spp0 + sl, go, gd);
+                        generate_ray(a, tile_pixel(a.pix0 + pl, a.tiles_x, a.width), a.spp0 + sl, go, gd);
                         stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
@@ -843,11 +856,12 @@ __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_BVH_WAVES) k_trace_bvh(TraceA
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
 __global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const float4 *__restrict__ rad, float *__restrict__ sum,
-                                                           uint32_t pix0, uint32_t npix, uint32_t nsamp, uint32_t overwrite)
+                                                           uint32_t pix0, uint32_t npix, uint32_t nsamp, uint32_t overwrite,
+                                                           uint32_t tiles_x, uint32_t width)
 {
     uint32_t pl = blockIdx.x * MIRT_BLOCK + threadIdx.x;
     if (pl >= npix) return;
-    float *s = sum + 3 * (size_t)(pix0 + pl);
+    float *s = sum + 3 * (size_t)tile_pixel(pix0 + pl, tiles_x, width);
     f3 acc = overwrite ? mk(0.0f, 0.0f, 0.0f) : mk(s[0], s[1], s[2]);
     if (overwrite) { float4 r = rad[pl]; acc = mk(r.x, r.y, r.z); }
     else for (uint32_t k = 0; k < nsamp; ++k) { float4 r = rad[(size_t)k * npix + pl]; acc = acc + mk(r.x, r.y, r.z); }

@@ -205,6 +205,27 @@ def test_batching_and_ranges(gpu, orc):
     H.assert_bits(part, osum, "oracle ranges")
 
 
+def test_tiled_path_ids(gpu, orc):
+    """With a BVH walk the persistent engine enumerates pixels in 8x8 tiles (option tile_paths, rt_kernels.h tile_pixel).
+    That only changes which lane traces which path: the image must equal the row-order one and the oracle's, also when
+    the batches cut the image into pixel ranges that end inside a tile, and for sizes that are no multiple of 8
+    (tiling off by itself)."""
+    s, cam = scene.spheres_world(64 / 48)
+    capi.build_bvh(s)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    for (w, h) in ((64, 48), (40, 24), (36, 20)):
+        osum, ost = orc.trace(s, cam, w, h, 5, 50, 21, 0)
+        for flags in (0, capi.FLAG_ACCEL_ORDERED):
+            for tiles in (1, 0):
+                gpu.set_option("tile_paths", tiles)
+                for max_paths in (1 << 30, max(w * h + 13, 1024), 1029):
+                    gpu.set_option("max_paths", max_paths)
+                    g = gpu.render(w, h, 5, 50, 21, flags)
+                    H.assert_bits(g["sum"], osum, f"{w}x{h} flags={flags} tile_paths={tiles} max_paths={max_paths}")
+                    assert g["stats"].rays == ost.rays
+    gpu.set_option("tile_paths", 1); gpu.set_option("max_paths", 1 << 30)
+
+
 def test_depth_limits(gpu, orc):
     s, cam = scene.cornell_box(1.0)
     gpu.upload_scene(s); gpu.set_camera(cam)
