@@ -864,7 +864,19 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const float4 *__restr
     float *s = sum + 3 * (size_t)tile_pixel(pix0 + pl, tiles_x, width);
     f3 acc = overwrite ? mk(0.0f, 0.0f, 0.0f) : mk(s[0], s[1], s[2]);
     if (overwrite) { float4 r = rad[pl]; acc = mk(r.x, r.y, r.z); }
-    else for (uint32_t k = 0; k < nsamp; ++k) { float4 r = rad[(size_t)k * npix + pl]; acc = acc + mk(r.x, r.y, r.z); }
+    else {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 *p = (const f32x4 *)rad + pl;
+        uint32_t k = 0;
+        for (; k + 8u <= nsamp; k += 8u) {                         // eight loads in flight, then the ordered adds; read once: no reuse
+            f32x4 r[8];
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) r[j] = __builtin_nontemporal_load(p + (size_t)(k + j) * npix);
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; ++j) acc = acc + mk(r[j].x, r[j].y, r[j].z);
+        }
+        for (; k < nsamp; ++k) { f32x4 r = p[(size_t)k * npix]; acc = acc + mk(r.x, r.y, r.z); }
+    }
     s[0] = acc.x; s[1] = acc.y; s[2] = acc.z;
 }
 
