@@ -428,6 +428,12 @@ __device__ __forceinline__ void generate_ray(const Args &a, uint32_t pixel, uint
     camera_ray(a.cam, u, v, p, o, d);
 }
 
+// Set bits of a wave mask below this lane (v_mbcnt_lo + v_mbcnt_hi: two instructions, no lane mask to build)
+__device__ __forceinline__ uint32_t rank_in(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // ---------------------------------------------------------------------------------- wave-cooperative draws
 // Rejection sampling of the unit sphere (Randomizer.h:40-48) accepts 52 % of its candidates, so a wave
 // whose lanes each loop "until mine is accepted" runs ~6 rounds with a third of its lanes working.
@@ -476,7 +482,7 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const uint32_t n = (uint32_t)__popcll(mask);
         const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per pending lane
         const uint32_t G = 1u << lg;
-        const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        const uint32_t rank = rank_in(mask);
         if (pending) { cl.pix[rank] = pixel; cl.smp[rank] = sample; cl.it[rank] = next_it; if (LSTAGE) cl.stg[rank] = stage; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -495,7 +501,8 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const uint32_t src = got ? (rank << lg) + (uint32_t)__builtin_ctz(bits | 0x80000000u) : lane;
         next_it += (pending & !got) ? G : 0u;
         const uint32_t c0 = (uint32_t)__shfl((int)r[0], (int)src), c1 = (uint32_t)__shfl((int)r[1], (int)src), c2 = (uint32_t)__shfl((int)r[2], (int)src);
-        if (got) { w0 = c0; w1 = c1; w2 = c2; pending = false; }
+        w0 = got ? c0 : w0; w1 = got ? c1 : w1; w2 = got ? c2 : w2;
+        pending = pending & !got;
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
     }
     if (need == NEED_SPHERE) sphere_pt = mk(map_pm1(w0), map_pm1(w1), map_pm1(w2));
@@ -696,7 +703,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     lds_stage(a.sc, lv);                                            // ends with a barrier
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     auto &stash = s_stash[wave];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // wave-uniform bookkeeping
     uint32_t cnt = 0;                       // rays in the stash
@@ -736,7 +742,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             // ---- idle lanes take a fresh path from the top of the stash
             const unsigned long long idle = __ballot(!live);
             if (idle != 0ull && cnt != 0u) {
-                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                const uint32_t rank = rank_in(idle);
                 if (!live && rank < cnt) {
                     const uint32_t e = cnt - 1u - rank;
                     const float4 qa = stash.a[e], qb = stash.b[e];
@@ -755,7 +761,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             const unsigned long long idle = __ballot(!live);
             if (idle != 0ull && (cnt != 0u || !exhausted)) {
                 const uint32_t n_idle = (uint32_t)__popcll(idle);
-                const uint32_t rank = (uint32_t)__popcll(idle & lt_mask);
+                const uint32_t rank = rank_in(idle);
                 uint32_t served = 0;
                 for (;;) {
                     const uint32_t take = (n_idle - served < cnt) ? n_idle - served : cnt;
