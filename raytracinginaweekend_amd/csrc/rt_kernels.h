@@ -498,9 +498,12 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const unsigned long long am = __ballot(acc);
         const uint32_t bits = (uint32_t)(am >> (rank << lg)) & ((1u << G) - 1u);   // this lane's G helpers, lowest = earliest iteration
         const bool got = pending & (bits != 0u);
-        const uint32_t src = got ? (rank << lg) + (uint32_t)__builtin_ctz(bits | 0x80000000u) : lane;
+        // byte address of the helper lane for ds_bpermute (what __shfl computes, minus its width arithmetic); the find-first
+        // of an empty set is used only under `got`
+        const int src4 = (int)((got ? (rank << lg) + (uint32_t)__builtin_ctz(bits) : lane) << 2);
         next_it += (pending & !got) ? G : 0u;
-        const uint32_t c0 = (uint32_t)__shfl((int)r[0], (int)src), c1 = (uint32_t)__shfl((int)r[1], (int)src), c2 = (uint32_t)__shfl((int)r[2], (int)src);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[0]), c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[1]),
+                       c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[2]);
         w0 = got ? c0 : w0; w1 = got ? c1 : w1; w2 = got ? c2 : w2;
         pending = pending & !got;
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
