@@ -122,12 +122,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # one extra, untimed, instrumented step: per-launch HIP events on the render stream + ray counts
+    # a few extra, untimed, instrumented steps: per-launch HIP events on the render stream + ray counts; the launch
+    # times are averaged over them (a single launch can be off by several per cent)
     ctx.set_option("time_launches", 1)
-    st = capi.Stats()
-    step(st)
-    torch.cuda.synchronize(dev)
-    reduce_ms = float(ev[0].elapsed_time(ev[1])) if dist is not None else 0.0     # the one exchange of the path, rank 0's view
+    n_inst = max(1, min(args.steps, 3))
+    st = None
+    ext_ms, ext_launches, dev_ms, reduce_ms = 0.0, 0, 0.0, 0.0
+    for _ in range(n_inst):
+        st = capi.Stats()
+        step(st)
+        torch.cuda.synchronize(dev)
+        ext_ms += st.extend_ms; ext_launches += int(st.extend_launches); dev_ms += st.device_ms
+        if dist is not None:
+            reduce_ms += float(ev[0].elapsed_time(ev[1]))       # the one exchange of the path, rank 0's view
+    reduce_ms /= n_inst
     ctx.set_option("time_launches", 0)
     rays_local = torch.tensor([float(st.rays), float(st.samples)], dtype=torch.float64, device=dev)
     if dist is not None:
@@ -142,8 +150,8 @@ def main():
         # dominant kernel: k_trace (engine 1: one launch per batch, every bounce of every path) or k_bounce at
         # depth >= 1 (engine 0); rank 0's launches, HIP events on their stream
         hist = list(st.depth_hist)
-        launches = max(1, int(st.extend_launches))
-        k_s = st.extend_ms * 1e-3
+        launches = max(1, int(st.extend_launches))                 # per render
+        k_s = ext_ms / n_inst * 1e-3                               # k_trace time per render, mean of the instrumented renders
         if args.engine == 1:
             kname = "k_trace<true,false>"
             k_rays = float(st.rays)
@@ -165,7 +173,7 @@ def main():
                 traffic = round(pm["hbm_bytes_per_launch"] * (float(st.samples) / launches) / pm["paths_per_launch"], 1)
         except (OSError, ValueError):
             pass
-        common = {"kernel": kname, "launches": launches, "avg_launch_ms": round(st.extend_ms / launches, 4)}
+        common = {"kernel": kname, "launches": launches, "avg_launch_ms": round(ext_ms / max(1, ext_launches), 4), "timed_launches": ext_launches}
         valu = {"bound": "valu", "achieved": round(valu_achieved, 4), "peak": round(VALU_PEAK_TOPS, 1), "unit": "TFLOP/s",
                 "frac": round(valu_achieved / VALU_PEAK_TOPS, 5), "traffic": traffic, **common,
                 "flop_per_ray": FLOP_PER_RAY, "flop_per_launch": round(k_flop / launches, 1)}
@@ -185,7 +193,7 @@ def main():
                        "engine": "persistent (k_trace)" if args.engine == 1 else "wavefront (k_bounce per depth)"},
             "mrays_per_s": round(msamples * rays_per_sample, 2), "rays_per_sample": round(rays_per_sample, 4),
             "roofline": roofline, "roofline_other": other,
-            "whole_render": {"device_ms_rank0": round(st.device_ms, 3), "dominant_kernel_ms": round(st.extend_ms, 3),
+            "whole_render": {"device_ms_rank0": round(dev_ms / n_inst, 3), "dominant_kernel_ms": round(ext_ms / n_inst, 3),
                              "batches": int(st.batches), "launches": int(st.bounce_launches),
                              "rccl_reduce_ms": round(reduce_ms, 3), "reduce_bytes": int(W) * H * 3 * 4 if world > 1 else 0},
         }
