@@ -52,6 +52,8 @@ struct mirt_ctx {
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
+    int32_t walk_yield = -1;                // near-first walks in slices that end when this many lanes of a wave have finished;
+                                            // 0: off, -1 (default): 56 for scenes of 65536 objects or more (+10 % on 1M spheres, -7 % on 485)
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
     uint32_t stack_lds = 2;                // traversal-stack levels kept in LDS (1 KiB each); likewise
@@ -125,6 +127,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "lds_prims")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_prims out of range"); c->lds_prims = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "walk_yield")) { if (value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "walk_yield out of range"); c->walk_yield = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
@@ -348,12 +351,13 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
     do {                                                                                                          \
         if (mode == 0) { if (pl) { if (tex) { CALL(0, true, true); } else { CALL(0, true, false); } } else { if (tex) { CALL(0, false, true); } else { CALL(0, false, false); } } }      \
         else if (mode == 1) { if (pl) { if (tex) { CALL(1, true, true); } else { CALL(1, true, false); } } else { if (tex) { CALL(1, false, true); } else { CALL(1, false, false); } } } \
-        else { if (pl) { if (tex) { CALL(2, true, true); } else { CALL(2, true, false); } } else { if (tex) { CALL(2, false, true); } else { CALL(2, false, false); } } }                \
+        else if (mode == 2) { if (pl) { if (tex) { CALL(2, true, true); } else { CALL(2, true, false); } } else { if (tex) { CALL(2, false, true); } else { CALL(2, false, false); } } } \
+        else { if (pl) { if (tex) { CALL(3, true, true); } else { CALL(3, true, false); } } else { if (tex) { CALL(3, false, true); } else { CALL(3, false, false); } } }                \
     } while (0)
 
 static uint32_t trace_lds(const mirt_ctx *c, int mode)
 {
-    return mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
+    return mode >= 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
 }
 static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
 {
@@ -381,6 +385,8 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_sum, hipStream_t st, mirt_stats *stats,
                              int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp)
 {
+    const uint32_t yield_want = c->walk_yield >= 0 ? (uint32_t)c->walk_yield : (c->sc.n_objects >= 65536u ? 56u : 0u);
+    if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
     const uint64_t npix_total = (uint64_t)p->width * p->height;
     const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
@@ -400,7 +406,8 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
 
     TraceArgs a{};
-    a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    a.sc = mode >= 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
+    a.slice_want = yield_want;
     if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);

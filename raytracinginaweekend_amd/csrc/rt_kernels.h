@@ -385,6 +385,58 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     return best;
 }
 
+// The same near-first walk as a resumable slice (ACCEL 3, option walk_yield).  Walks of one wave differ 2-3x in
+// length, and a wave that waits for its longest walk leaves most lanes idle.  Here the wave leaves the walk loop as
+// soon as `want` of the lanes that entered have finished; those are shaded (and start their next ray) while the
+// others keep their walk -- node, stack pointer, t_max, best, 1/dir -- for the next slice.  The per-lane stack lives in
+// LDS/HBM slots indexed by lane, so it survives between slices by itself.  Per-path arithmetic is unchanged.
+struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
+
+template <bool PLDS>
+__device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, bool &act, uint32_t want)
+{
+    Stack stk(sc, v);
+    stk.sp = w.sp;
+    int32_t cur = w.cur;
+    const PrimRec *P = PLDS ? v.prims : sc.prims;
+    const f3 invd = w.invd;
+    const unsigned long long entered = __ballot(act);
+    for (;;) {
+        if (act) {
+            bool down = false;
+            if (cur >= 0) {
+                Node2 n;
+                const float4 *g = (const float4 *)(sc.nodes2 + cur);
+                float4 a = g[0], b = g[1], c = g[2], e = g[3];
+                n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
+                n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
+                n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
+                float tl = 0.0f, tr = 0.0f;
+                const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, w.t_max, n.left, tl);
+                const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, w.t_max, n.right, tr);
+                if (hl && hr) {
+                    const bool left_first = tl <= tr;
+                    stk.push(left_first ? n.right : n.left);
+                    cur = left_first ? n.left : n.right;
+                    down = true;
+                } else if (hl) { cur = n.left; down = true; }
+                else if (hr) { cur = n.right; down = true; }
+            } else if (cur != MIRT_CHILD_NONE) {
+                uint32_t first = (uint32_t)~cur, cnt = 1;
+                if (!sc.single) { uint2 ob = sc.objs[~cur]; first = ob.x; cnt = ob.y; }    // Object::Hit, SimpleObject.cpp:73-83
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    float t;
+                    if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                }
+            }
+            if (!down) { if (stk.sp == 0) act = false; else cur = stk.pop(); }
+        }
+        const unsigned long long still = __ballot(act);
+        if (still == 0ull || (uint32_t)__popcll(entered & ~still) >= want) break;
+    }
+    w.cur = cur; w.sp = stk.sp;
+}
+
 // Path ids enumerate pixels tile by tile (8x8) rather than row by row, so the 64 camera rays a wave generates at
 // once cover a compact patch: their walks through a BVH stay together longer.  A bijection on the image (both sides
 // multiples of 8; tiles_x = 0 turns it off); the pixel it returns is the real one -- the Philox key, the camera ray,
@@ -669,6 +721,7 @@ struct TraceArgs {
     uint32_t width, height, pix0, npix, spp0;
     uint32_t max_depth, flags, k0, k1;
     uint32_t tiles_x;              // > 0: path ids run over 8x8 pixel tiles (tile_pixel), tiles_x = width / 8
+    uint32_t slice_want;           // ACCEL 3: finished walks that end a slice (bvh2_slice)
 };
 // 128 entries: topped up whenever fewer than 64 remain, so one pass always serves every idle lane (list walk:
 // the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
@@ -689,6 +742,9 @@ __device__ __forceinline__ void wave_lds_sync()
 #endif
 #ifndef MIRT_LIST_WAVES
 #define MIRT_LIST_WAVES 7
+#endif
+#ifndef MIRT_YIELD_WAVES
+#define MIRT_YIELD_WAVES 6   // the yielding walk keeps its walk state live through the shading code
 #endif
 template <int ACCEL, bool PLDS, bool TEX>
 __device__ __forceinline__ void trace_body(const TraceArgs &a)
@@ -715,6 +771,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     bool live = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
     uint32_t pid = 0, pixel = 0, sample = 0, depth = 0;
+    WalkState ws; ws.cur = 0; ws.best = -1; ws.t_max = 0.0f; ws.sp = 0; ws.invd = mk(0, 0, 0);   // ACCEL 3 only
+    bool walking = false;
 
     for (;;) {
         if constexpr (BIG_STASH) {
@@ -809,11 +867,25 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         Hit h;                                 // set where `need`/`done` are decided below; read only under `live && !done`
         const MatRec *M;
         if constexpr (ACCEL != 0) { h.pos = o; h.nrm = d; h.mat = 0; M = a.sc.mats; radiance = mk(0.0f, 0.0f, 0.0f); }   // under the 64-register cap of the BVH kernels defined values allocate better (fewer spills)
-        if (live) {
+        bool ready = live;                      // lanes whose closest hit is known in this iteration
+        if constexpr (ACCEL == 3) {
+            if (live) {
+                if (!walking) {
+                    ws.cur = a.sc.root; ws.best = -1; ws.t_max = 3.402823466e+38f; ws.sp = 0;
+                    ws.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
+                    walking = true;
+                }
+                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, walking, a.slice_want);
+            }
+            ready = live && !walking;
+        }
+        if (ready) {
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
-            const int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
-                               : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
+            int32_t best;
+            if constexpr (ACCEL == 3) { best = ws.best; t_max = ws.t_max; }
+            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
+                      : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
             } else {
@@ -836,20 +908,20 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
         coop_draws<true>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
         // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
-        if (live && !done) {
+        if (ready && !done) {
             Scat s;
             const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
             scatter_finish<ACCEL != 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
-        if (live && done) {
+        if (ready && done) {
             a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
             atomicAdd(&s_hist[depth < 63u ? depth : 63u], 1u);
             if (depth > 63u) atomicAdd(&s_hist[64], depth - 63u);
             live = false;
         }
-        ++depth;
+        if (ready) ++depth;
     }
     __syncthreads();
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
@@ -860,7 +932,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 template <bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
 template <int ACCEL, bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
+__global__ void __launch_bounds__(MIRT_BLOCK, ACCEL == 3 ? MIRT_YIELD_WAVES : MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).

@@ -228,6 +228,35 @@ def test_tiled_path_ids(gpu, orc):
     gpu.set_option("tile_paths", 1); gpu.set_option("max_paths", 1 << 30)
 
 
+def test_yielding_walk(gpu, orc):
+    """Option walk_yield: the near-first walk in resumable slices (rt_kernels.h bvh2_slice) -- a wave leaves the walk
+    loop when that many lanes have finished, shades them and resumes the rest.  Only the schedule changes: images
+    and ray counts equal the oracle's, and the rays per depth are the same for every setting, across batch cuts."""
+    s, cam = scene.spheres_world(64 / 48)
+    capi.build_bvh(s)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w, h = 64, 48
+    osum, ost = orc.trace(s, cam, w, h, 6, 50, 33, 0)
+    ref_hist = None
+    try:
+        for wy in (0, 1, 7, 32, 56, 64):
+            gpu.set_option("walk_yield", wy)
+            for max_paths in (1 << 30, 2048):
+                gpu.set_option("max_paths", max_paths)
+                g = gpu.render(w, h, 6, 50, 33, capi.FLAG_ACCEL_ORDERED)
+                H.assert_bits(g["sum"], osum, f"walk_yield={wy} max_paths={max_paths}")
+                assert g["stats"].rays == ost.rays
+                hist = list(g["stats"].depth_hist)
+                ref_hist = hist if ref_hist is None else ref_hist
+                assert hist == ref_hist                                      # rays per depth, whatever the schedule
+        gpu.set_option("walk_yield", 3)
+        g = gpu.render(w, h, 2, 2, 33, capi.FLAG_ACCEL_ORDERED)              # depth limit inside the yielding loop
+        osum2, _ = orc.trace(s, cam, w, h, 2, 2, 33, 0)
+        H.assert_bits(g["sum"], osum2, "walk_yield with max_depth 2")
+    finally:
+        gpu.set_option("walk_yield", -1); gpu.set_option("max_paths", 1 << 30)
+
+
 def test_depth_limits(gpu, orc):
     s, cam = scene.cornell_box(1.0)
     gpu.upload_scene(s); gpu.set_camera(cam)
