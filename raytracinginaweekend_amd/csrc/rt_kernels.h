@@ -927,8 +927,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
 }
 
-// The list walk is VALU-bound and lives with 7 waves per SIMD; the BVH walks wait on node fetches, so they are
-// compiled for 8 waves per SIMD (<= 64 VGPRs; a three-dword spill) and launched with a small LDS plan.
+// The list walk is VALU-bound and compiled for 7 waves per SIMD (72 VGPRs, no spill; 8 would spill and lose).  The
+// BVH walks are bound by the CU's L1 and indifferent to 6..8 waves: 8 (64 VGPRs) for the plain walks, 6 for the
+// yielding one, which keeps its walk state in registers through the shading code.  All launch with a small LDS plan.
 template <bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
 template <int ACCEL, bool PLDS, bool TEX>
