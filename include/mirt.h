@@ -99,7 +99,7 @@ typedef struct mirt_hit {
 #define MIRT_FLAG_NORMAL_DISPLAY 2u  /* m_enableNormalDisplay, HomemadeRayTracer.cpp:164-167 */
 #define MIRT_FLAG_ACCEL_LIST     4u  /* closest hit by a linear pass over all objects instead
                                         of the BVH (what HitableCombo::Hit does, Hitables.cpp:130-142) */
-#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for scenes of up to 48 primitives, ORDERED otherwise */
+#define MIRT_FLAG_ACCEL_AUTO     16u /* library picks LIST for scenes of up to 32 primitives, ORDERED otherwise */
 #define MIRT_FLAG_ACCEL_ORDERED  32u /* walk the BVH nearer child first instead of the reference's
                                         left-then-right order (SimpleObject.cpp:394-402): same closest
                                         t, far fewer boxes; only the winner of an exact tie can differ.
@@ -155,7 +155,7 @@ int         mirt_device_count(void);
  *                   up to which the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS
  *                   (default 2, the rest spills to HBM), largest material table staged (default 1024 bytes),
  *                   largest primitive table staged (default 4096 bytes; such scenes are walked as a list under
- *                   MIRT_FLAG_ACCEL_AUTO when they have at most 48 primitives) */
+ *                   MIRT_FLAG_ACCEL_AUTO when they have at most 32 primitives) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 
 /* -- scene ---------------------------------------------------------------------------------- */

@@ -306,7 +306,7 @@ extern "C" int mirt_set_camera(mirt_ctx *c, const mirt_camera *cam)
 static int accel_mode(const mirt_ctx *c, uint32_t flags)
 {
     if (flags & MIRT_FLAG_ACCEL_LIST) return 0;
-    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 48 && c->small_scene) ? 0 : 2;
+    if (flags & MIRT_FLAG_ACCEL_AUTO) return (c->sc.n_prims <= 32 && c->small_scene) ? 0 : 2;   // tools/crossover.py: the list wins up to ~30 primitives
     if (flags & MIRT_FLAG_ACCEL_ORDERED) return 2;
     return 1;
 }
