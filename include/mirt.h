@@ -179,6 +179,17 @@ int mirt_set_camera(mirt_ctx *ctx, const mirt_camera *cam);
  * stream).  Synchronises the stream before returning when stats != NULL. */
 int mirt_render_device(mirt_ctx *ctx, const mirt_render_params *p, float *d_sum_rgb,
                        void *stream, mirt_stats *stats);
+/* mirt_render_device for callers that cannot allocate.  No counterpart in the reference (its TraceRay new[]s its
+ * own buffer, HomemadeRayTracer.cpp:103): this entry point is for code under HIP-graph capture, tight serving loops
+ * and harnesses that forbid hipMalloc.  Same kernels, same arguments (no statistics), same bits in d_sum_rgb; the
+ * radiance slots, claim counters and the HBM part of the traversal stacks live in a fixed 64 MiB array in the
+ * library's device image (one copy per GPU, held until the process ends) instead of hipMalloc'ed buffers, and the
+ * call makes no hipMalloc / hipFree / allocating library call.  Limits (MIRT_ERR_ARG with a message beyond them):
+ * batches of 2 Mi paths, at most 3971 batches per call (width*height*spp_count <= ~8.3e9), 31 MiB of stack spill
+ * (always enough for a list walk; a BVH deeper than the LDS stack part needs (depth+1-stack_lds) * 4 bytes per
+ * resident lane).  Persistent engine only.  Every call on a GPU shares that GPU's array: calls that overlap on one
+ * GPU (two streams, two contexts, two threads) race -- serialise them. */
+int mirt_render_device_noalloc(mirt_ctx *ctx, const mirt_render_params *p, float *d_sum_rgb, void *stream);
 /* The tail of TraceRay + OutputImage::Render (HomemadeRayTracer.cpp:134-138, OutputImage.cpp:62-88):
  * mean over spp_total (skipped for ONE_SPP), per-channel sqrt, clamp, (UINT32)(c*255.0f)&0xFF, A=255.
  * d_pixels (device, w*h*3 post-gamma floats) and d_rgba8 (device, w*h*4) may each be NULL. */

@@ -65,7 +65,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", 
 
 EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
-    "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
+    "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_render_device_noalloc", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
     "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_tex_sample_batch", "mirt_write_ppm", "mirt_write_image",
 ]
@@ -97,6 +97,7 @@ def load():
     lib.mirt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
     lib.mirt_build_bvh.argtypes = [C.POINTER(SceneStruct), C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mirt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
+    lib.mirt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
     lib.mirt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mirt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.mirt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
@@ -198,6 +199,11 @@ class Context:
         self._ck(self.lib.mirt_render_device(self.h, C.byref(params), C.c_void_p(d_sum_ptr),
                                              C.c_void_p(stream) if stream else None,
                                              C.byref(stats) if stats is not None else None), "mirt_render_device")
+
+    def render_device_noalloc(self, params, d_sum_ptr, stream=None):
+        """mirt_render_device_noalloc: same image, scratch in the library's fixed device array, no allocation."""
+        self._ck(self.lib.mirt_render_device_noalloc(self.h, C.byref(params), C.c_void_p(d_sum_ptr),
+                                                     C.c_void_p(stream) if stream else None), "mirt_render_device_noalloc")
 
     def resolve_device(self, d_sum_ptr, width, height, spp_total, flags, d_pixels_ptr=None, d_rgba8_ptr=None, stream=None):
         self._ck(self.lib.mirt_resolve_device(self.h, C.c_void_p(d_sum_ptr), width, height, spp_total, flags,

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "rt_kernels.h"
@@ -27,6 +28,28 @@ struct DevBuf {
         bytes = n; return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+// mirt_render_device_noalloc: the persistent engine's scratch (radiance slots, claim cursors + path-length histograms,
+// the HBM part of the traversal stacks) in a file-scope device array instead of hipMalloc'ed buffers.  Every GPU the
+// library runs on holds its own copy until the process ends.  In host code the array's NAME is only a handle for
+// hipGetSymbolAddress: the address kernels and hipMemsetAsync get is g_scratch_ptr[device], looked up once per
+// device in mirt_create with that device current.
+constexpr size_t SCRATCH_RAD_PATHS = 2u << 20;                       // 2 Mi paths per batch: 32 MiB of float4 slots
+constexpr size_t SCRATCH_RAD_BYTES = SCRATCH_RAD_PATHS * sizeof(float4);
+constexpr size_t SCRATCH_COUNTS_BYTES = 1u << 20;                    // 66 words per batch: up to 3971 batches per call
+constexpr size_t SCRATCH_SPILL_BYTES = 31u << 20;                    // traversal-stack levels beyond the LDS part
+constexpr size_t SCRATCH_BYTES = SCRATCH_RAD_BYTES + SCRATCH_COUNTS_BYTES + SCRATCH_SPILL_BYTES;   // 64 MiB
+constexpr int SCRATCH_MAX_DEVICES = 64;
+__device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+unsigned char *g_scratch_ptr[SCRATCH_MAX_DEVICES];                   // written under g_scratch_mu, never cleared
+std::mutex g_scratch_mu;
+
+// Where one render keeps its scratch: hipMalloc'ed buffers of the context (grown on demand) or a carving of `scratch`.
+struct Workspace {
+    float4 *rad; size_t rad_paths;
+    uint32_t *counts; size_t counts_bytes;
+    int32_t *spill; size_t spill_bytes;
 };
 
 } // namespace
@@ -60,6 +83,7 @@ struct mirt_ctx {
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
+    unsigned char *scratch_dev = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress in mirt_create)
 };
 
 #define HIPCHK(ctx, call)                                                                     \
@@ -95,6 +119,18 @@ extern "C" int mirt_create(int device_id, mirt_ctx **out)
     c->device = device_id;
     c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { g_create_error = "hipEventCreate failed"; delete c; return MIRT_ERR_HIP; }
+    if (device_id < SCRATCH_MAX_DEVICES) {                      // device `device_id` is current (hipSetDevice above)
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[device_id]) {
+            void *sp = nullptr;
+            if ((e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch))) != hipSuccess || !sp) {
+                g_create_error = std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e);
+                (void)hipEventDestroy(c->ev0); (void)hipEventDestroy(c->ev1); delete c; return MIRT_ERR_HIP;
+            }
+            g_scratch_ptr[device_id] = (unsigned char *)sp;
+        }
+        c->scratch_dev = g_scratch_ptr[device_id];
+    }
     *out = c;
     return MIRT_OK;
 }
@@ -382,33 +418,52 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 }
 
 // The persistent engine: one k_trace launch + one k_accumulate per batch; no queues.
+// fixed: the scratch of mirt_render_device_noalloc (nothing is allocated, sizes beyond it are errors); NULL: the
+// context's own buffers, grown on demand.
 static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_sum, hipStream_t st, mirt_stats *stats,
-                             int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp)
+                             int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp, const Workspace *fixed = nullptr)
 {
     const uint32_t yield_want = c->walk_yield >= 0 ? (uint32_t)c->walk_yield : (c->sc.n_objects >= 65536u ? 56u : 0u);
     if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
     const uint64_t npix_total = (uint64_t)p->width * p->height;
-    const uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
+    uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
+    if (fixed) cap = std::min<uint64_t>(cap, fixed->rad_paths);
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
     const size_t capq = (size_t)npix_b * S;
     const uint32_t n_pix_tiles = (uint32_t)((npix_total + npix_b - 1) / npix_b);
     const uint32_t n_s_tiles = (spp_count + S - 1) / S;
-    const uint32_t n_batches = n_pix_tiles * n_s_tiles;
+    const uint64_t n_batches64 = (uint64_t)n_pix_tiles * n_s_tiles;
+    const size_t per_batch = 66;                           // cursor, hist[65]
+    if (n_batches64 > 0x7FFFFFFFull / per_batch) return fail(c, MIRT_ERR_ARG, "mirt_render_device: too many batches (raise the max_paths option)");
+    const uint32_t n_batches = (uint32_t)n_batches64;
     const uint32_t per_cu = c->blocks_per_cu ? c->blocks_per_cu : trace_occupancy(c, mode);
     if (getenv("MIRT_DEBUG")) fprintf(stderr, "[mirt] persistent engine, mode %d, lds %u B, %u workgroups/CU (occupancy query %u)\n", mode, trace_lds(c, mode), per_cu, trace_occupancy(c, mode));
     const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
-    const size_t per_batch = 66;                           // cursor, hist[65]
-    if (c->d_rad.ensure(capq * sizeof(float4)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
-        return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the radiance slots failed (lower the max_paths option)");
-    uint32_t *counts = (uint32_t *)c->d_counts.p;
+    TraceArgs a{};
+    a.sc = mode >= 2 ? c->sc2 : c->sc; a.cam = c->cam;
+    a.slice_want = yield_want;
+    uint32_t *counts;
+    if (fixed) {
+        // nothing is allocated on this path: every size is checked against the fixed scratch instead
+        const size_t spill_levels = a.sc.stack_depth - a.sc.stack_lds;
+        if (n_batches * per_batch * sizeof(uint32_t) > fixed->counts_bytes)
+            return fail(c, MIRT_ERR_ARG, "mirt_render_device_noalloc: width*height*spp_count needs " + std::to_string(n_batches) + " batches of 2 Mi paths; the fixed scratch holds the counters of " +
+                                         std::to_string(fixed->counts_bytes / (per_batch * sizeof(uint32_t))) + " (render fewer samples per call)");
+        if (spill_levels * max_grid * MIRT_BLOCK * sizeof(int32_t) > fixed->spill_bytes)
+            return fail(c, MIRT_ERR_ARG, "mirt_render_device_noalloc: the BVH is " + std::to_string(a.sc.stack_depth - 1) + " levels deep and its traversal stacks need " +
+                                         std::to_string(spill_levels * max_grid * MIRT_BLOCK * sizeof(int32_t)) + " bytes of scratch; the fixed scratch has " + std::to_string(fixed->spill_bytes) +
+                                         " (use mirt_render_device, or lower the blocks_per_cu option)");
+        a.rad = fixed->rad; counts = fixed->counts;
+        a.sc.spill = fixed->spill; a.sc.spill_stride = max_grid * MIRT_BLOCK;
+    } else {
+        if (c->d_rad.ensure(capq * sizeof(float4)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
+            return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the radiance slots failed (lower the max_paths option)");
+        a.rad = (float4 *)c->d_rad.p; counts = (uint32_t *)c->d_counts.p;
+        if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
+    }
     HIPCHK(c, hipMemsetAsync(counts, 0, n_batches * per_batch * sizeof(uint32_t), st));
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
-
-    TraceArgs a{};
-    a.sc = mode >= 2 ? c->sc2 : c->sc; a.cam = c->cam; a.rad = (float4 *)c->d_rad.p;
-    a.slice_want = yield_want;
-    if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     // BVH walks gain ~2 % from compact 8x8 patches of camera rays; the list walk loses ~3 % (paths of one patch end together)
@@ -432,7 +487,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             launch_trace(c, mode, a, grid, st);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch + 1], st));
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
-                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u, a.tiles_x, a.width);
+                               (const float4 *)a.rad, d_sum, pix0, np, ns, one_spp ? 1u : 0u, a.tiles_x, a.width);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -466,18 +521,50 @@ static PathQ carve_queue(float4 *base, size_t cap)
     return q;
 }
 
-extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream, mirt_stats *stats)
+// The argument checks mirt_render_device and mirt_render_device_noalloc share.
+static int check_render_args(mirt_ctx *c, const mirt_render_params *p)
 {
-    if (!c || !p || !d_sum) return MIRT_ERR_ARG;
     if (!c->have_scene || !c->have_camera) return fail(c, MIRT_ERR_STATE, "mirt_render_device: upload a scene and set a camera first");
     if (!p->width || !p->height) return fail(c, MIRT_ERR_ARG, "mirt_render_device: empty image");
-    const uint64_t npix_total = (uint64_t)p->width * p->height;
-    if (npix_total > (1ull << 31)) return fail(c, MIRT_ERR_ARG, "mirt_render_device: image larger than 2^31 pixels");
+    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(c, MIRT_ERR_ARG, "mirt_render_device: image larger than 2^31 pixels");
     if (p->max_depth > 4096) return fail(c, MIRT_ERR_ARG, "mirt_render_device: max_depth > 4096");
+    if (!(p->flags & MIRT_FLAG_ONE_SPP) && (uint64_t)p->spp_begin + p->spp_count > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: sample index overflows 32 bits");
+    return MIRT_OK;
+}
+
+// mirt_render_device for callers that cannot allocate (HIP-graph capture, tight serving loops, harnesses that forbid
+// hipMalloc): the same kernels, their scratch carved out of the file-scope `scratch` array of this GPU.  Calls no
+// hipMalloc / hipFree / allocating routine.  The array is shared by every call on the GPU and keeps the last call's
+// contents: the counters are cleared on `stream` first (radiance slots and stack levels are written before they are
+// read), and calls that overlap on one GPU race.
+extern "C" int mirt_render_device_noalloc(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream)
+{
+    if (!c || !p || !d_sum) return MIRT_ERR_ARG;
+    int rc = check_render_args(c, p);
+    if (rc) return rc;
+    if (c->engine != 1) return fail(c, MIRT_ERR_STATE, "mirt_render_device_noalloc: the persistent engine only (option engine=1)");
+    if (!c->scratch_dev) return fail(c, MIRT_ERR_STATE, "mirt_render_device_noalloc: no scratch on this device (device id >= 64)");
     const bool one_spp = p->flags & MIRT_FLAG_ONE_SPP;
     const uint32_t spp_count = one_spp ? 1u : p->spp_count;
     const uint32_t spp_begin = one_spp ? 0u : p->spp_begin;
-    if ((uint64_t)spp_begin + spp_count > 0xFFFFFFFFull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: sample index overflows 32 bits");
+    if (spp_count == 0) return MIRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    Workspace w;
+    w.rad = (float4 *)c->scratch_dev; w.rad_paths = SCRATCH_RAD_PATHS;
+    w.counts = (uint32_t *)(c->scratch_dev + SCRATCH_RAD_BYTES); w.counts_bytes = SCRATCH_COUNTS_BYTES;
+    w.spill = (int32_t *)(c->scratch_dev + SCRATCH_RAD_BYTES + SCRATCH_COUNTS_BYTES); w.spill_bytes = SCRATCH_SPILL_BYTES;
+    return render_persistent(c, p, d_sum, (hipStream_t)stream, nullptr, accel_mode(c, p->flags), spp_begin, spp_count, one_spp, &w);
+}
+
+extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream, mirt_stats *stats)
+{
+    if (!c || !p || !d_sum) return MIRT_ERR_ARG;
+    int rc_args = check_render_args(c, p);
+    if (rc_args) return rc_args;
+    const uint64_t npix_total = (uint64_t)p->width * p->height;
+    const bool one_spp = p->flags & MIRT_FLAG_ONE_SPP;
+    const uint32_t spp_count = one_spp ? 1u : p->spp_count;
+    const uint32_t spp_begin = one_spp ? 0u : p->spp_begin;
     if (stats) memset(stats, 0, sizeof *stats);
     if (spp_count == 0) return MIRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
