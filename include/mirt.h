@@ -47,6 +47,7 @@ enum { MIRT_MAT_DIFFUSE_LIGHT = 0, MIRT_MAT_LAMBERTIAN = 1, MIRT_MAT_METAL = 2, 
  * All host pointers are borrowed for the duration of the call.
  */
 typedef struct mirt_scene {
+    uint32_t        struct_size; /* sizeof(mirt_scene) as the caller compiled it (see "ABI guard" below) */
     uint32_t        n_prims;
     const uint32_t *prim_kind;   /* MIRT_PRIM_*                                            */
     const float    *prim_off;    /* [3n] TranslatedInstance::m_offset, Hitables.h:87       */
@@ -106,6 +107,7 @@ typedef struct mirt_hit {
                                         No accel flag = the reference's order on the tree as given. */
 
 typedef struct mirt_render_params {
+    uint32_t struct_size;        /* sizeof(mirt_render_params) as the caller compiled it   */
     uint32_t width, height;      /* image->m_width/m_height, HomemadeRayTracer.cpp:100-101 */
     uint32_t spp_begin;          /* first global sample index rendered by this call        */
     uint32_t spp_count;          /* SAMPLE_PER_PIXEL (:21) made a run-time range           */
@@ -115,6 +117,8 @@ typedef struct mirt_render_params {
 } mirt_render_params;
 
 typedef struct mirt_stats {
+    uint32_t struct_size;        /* sizeof(mirt_stats) as the caller compiled it: set it BEFORE the call (the
+                                    library fills everything else and leaves this field alone) */
     uint64_t rays;               /* rays traced (exact: from the path-length histogram)    */
     uint64_t samples;            /* camera samples started                                 */
     uint64_t depth_hist[64];     /* rays per bounce index (0..63; deeper folded into 63)   */
@@ -131,6 +135,21 @@ typedef struct mirt_stats {
 } mirt_stats;
 
 typedef struct mirt_ctx mirt_ctx;
+
+/* -- ABI guard ------------------------------------------------------------------------------ */
+/* The structs above are filled on one side of the boundary and read on the other, so a host compiled against
+ * another revision of this header must get an error code, not a stack overrun (no reference counterpart: the
+ * reference is one executable).  Two layers:
+ *  - mirt_scene, mirt_render_params and mirt_stats begin with `struct_size`; every entry point that takes one
+ *    returns MIRT_ERR_ARG when it is not the size the library was built with (and writes nothing);
+ *  - a host checks everything once at load: `if (MIRT_CHECK_ABI() != MIRT_OK) refuse to run`.
+ * MIRT_ABI_VERSION is bumped whenever a struct, an enum value or a signature changes. */
+#define MIRT_ABI_VERSION 2u
+uint32_t mirt_abi_version(void);
+int      mirt_check_abi(uint32_t version, size_t sizeof_scene, size_t sizeof_camera, size_t sizeof_hit,
+                        size_t sizeof_render_params, size_t sizeof_stats);
+#define MIRT_CHECK_ABI() mirt_check_abi(MIRT_ABI_VERSION, sizeof(mirt_scene), sizeof(mirt_camera), sizeof(mirt_hit), \
+                                        sizeof(mirt_render_params), sizeof(mirt_stats))
 
 /* -- lifecycle ------------------------------------------------------------------------------ */
 /* Replaces `new HomemadeRayTracer(...)` + OnInit (RayTracer.cpp:129-130). */
@@ -209,6 +228,49 @@ int mirt_render(mirt_ctx *ctx, const mirt_render_params *p, float *h_sum_rgb, fl
 int mirt_render_progressive(mirt_ctx *ctx, const mirt_render_params *p, float *h_sum_rgb, float *h_pixels_rgb,
                             uint8_t *h_rgba8, mirt_stats *stats);
 
+/* -- multi-GPU: one render sharded over the GPUs of a node, inside one process ---------------- */
+/* The reference parallelises TraceRay over image rows with OpenMP threads and no communication
+ * (HomemadeRayTracer.cpp:107-110); it has no multi-device notion.  Here device g of G renders the global sample indices
+ * [g*spp/G, (g+1)*spp/G) of every pixel -- the Philox counter holds the global index, so the sample set does not
+ * depend on G -- with one host thread per device, the G radiance-sum buffers are summed onto device_ids[0] (the one
+ * exchange of the path) and that device resolves.  The image equals the one-device image up to the re-association of
+ * the per-pixel float sum.  (Processes that own one GPU each do the same with mirt_render_device + their own
+ * collective: bench.py, one rank per GPU, RCCL through torch.distributed.) */
+#define MIRT_MULTI_MAX_DEVICES 16
+#define MIRT_REDUCE_AUTO 0   /* RCCL when the devices are distinct and librccl.so loads, else PEER                       */
+#define MIRT_REDUCE_PEER 1   /* device 0 pulls every peer's buffer (hipMemcpyPeerAsync, one xGMI link each, side by side) and
+                                adds them in rank order: a fixed association, bit-reproducible for a given G; a device may be
+                                listed twice (contexts then share it) */
+#define MIRT_REDUCE_RCCL 2   /* one ncclReduce(sum, float32, root 0) per device in a group; distinct devices only          */
+typedef struct mirt_multi mirt_multi;
+typedef struct mirt_multi_info {
+    uint32_t struct_size;        /* sizeof(mirt_multi_info), set by the caller                                             */
+    uint32_t n_devices;
+    uint32_t reduce_kind;        /* MIRT_REDUCE_PEER / _RCCL as used; 0 with one device                                    */
+    uint32_t pad;
+    double   render_ms;          /* wall clock: all devices rendering (slowest one)                                        */
+    double   reduce_ms;          /* wall clock: the sum onto device 0                                                      */
+    double   resolve_ms;         /* wall clock: resolve + copies to the host outputs                                       */
+    uint64_t reduce_bytes;       /* size of one radiance-sum buffer                                                        */
+    int32_t  device[MIRT_MULTI_MAX_DEVICES];
+    uint32_t spp_begin[MIRT_MULTI_MAX_DEVICES], spp_count[MIRT_MULTI_MAX_DEVICES];
+    double   device_ms[MIRT_MULTI_MAX_DEVICES];   /* HIP-event time of each device's kernels                               */
+} mirt_multi_info;
+int         mirt_multi_create(const int *device_ids, int n, mirt_multi **out);
+void        mirt_multi_destroy(mirt_multi *m);
+const char *mirt_multi_last_error(const mirt_multi *m);               /* m may be NULL: last create error */
+int         mirt_multi_device_count(const mirt_multi *m);
+/* "reduce": MIRT_REDUCE_*; every other name goes to mirt_set_option of each device's context */
+int         mirt_multi_set_option(mirt_multi *m, const char *name, int64_t value);
+int         mirt_multi_upload_scene(mirt_multi *m, const mirt_scene *scene);     /* replicated on every device */
+int         mirt_multi_set_camera(mirt_multi *m, const mirt_camera *cam);
+/* rank's share of the samples [spp_begin, spp_begin+spp_count): the ranges of ranks 0..world-1 tile it in order */
+void        mirt_multi_spp_range(uint32_t rank, uint32_t world, uint32_t spp_begin, uint32_t spp_count, uint32_t *begin, uint32_t *count);
+/* Whole TraceRay over all devices; outputs as mirt_render (host pointers, each nullable).  stats: sums over the
+ * devices (device_ms/extend_ms: the slowest).  info (nullable): who rendered what and what the exchange cost. */
+int         mirt_multi_render(mirt_multi *m, const mirt_render_params *p, float *h_sum_rgb, float *h_pixels, uint8_t *h_rgba8,
+                              mirt_stats *stats, mirt_multi_info *info);
+
 /* -- function-level entry points (parity tests bind these; host pointers) -------------------- */
 /* AABB::Hit, AABB.cpp:5-21: out[i*nbox+b] = ray i vs box b */
 int mirt_aabb_hit_batch(mirt_ctx *ctx, const float *bmin, const float *bmax, size_t nbox,
@@ -217,7 +279,9 @@ int mirt_aabb_hit_batch(mirt_ctx *ctx, const float *bmin, const float *bmax, siz
 /* IHitable::Hit of one primitive's instance chain, Hitables.cpp:13-54,93-115,163-173,241-264 */
 int mirt_prim_hit_batch(mirt_ctx *ctx, uint32_t prim, const float *org, const float *dir,
                         size_t nray, float t_min, float t_max, mirt_hit *out);
-/* SimpleObjectBVHNode::Hit, SimpleObject.cpp:389-406 (flags: MIRT_FLAG_ACCEL_LIST for the list) */
+/* SimpleObjectBVHNode::Hit, SimpleObject.cpp:389-406 (flags: MIRT_FLAG_ACCEL_LIST for the list).  With an accel flag
+ * (LIST / AUTO / ORDERED) t_min must be > 0, as on the render path (0.001): those walks cull on the sign of the
+ * roots; MIRT_ERR_ARG otherwise.  Without one (the reference's order) any t_min is taken. */
 int mirt_world_hit_batch(mirt_ctx *ctx, const float *org, const float *dir, size_t nray,
                          float t_min, float t_max, uint32_t flags, mirt_hit *out);
 /* IMaterial::Scatter, Materials.cpp:19-33,99-106,172-217,260-264, with the raw 32-bit draws
@@ -235,10 +299,11 @@ int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32
 
 /* Arithmetic self-test of the device's IEEE building blocks (no reference counterpart; parity
  * tests bind it): op 0 x/y, 1 sqrt(x), 2 x^5 as Schlick evaluates it (Optics.h:31), 3 the [0,1)
- * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x, 5 x/y as the
- * rect test computes it (the division sequence with the denominator-only part shared between
- * the rects of one orientation, falling back to x/y outside its operand range), 6 whether op 5
- * used the shared sequence (1.0) or fell back (0.0).  y is required for ops 0, 5 and 6. */
+ * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x, 5 the raw shared-denominator
+ * division sequence of the rect test (the hardware's f32 division with the denominator-only part hoisted; it equals
+ * x/y bit for bit only inside its operand range and has NO fallback of its own -- the render kernel checks the range
+ * per ray and takes plain divides outside it), 6 whether (x, y) lies inside that range (1.0) or not (0.0).
+ * y is required for ops 0, 5 and 6. */
 int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
 /* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: uv = n (u,v) pairs -> n RGB triples of texture `tex` */
 int mirt_tex_sample_batch(mirt_ctx *ctx, uint32_t tex, const float *uv, size_t n, float *rgb_out);

@@ -42,6 +42,7 @@ enum { ORC_MAT_DIFFUSE_LIGHT = 0, ORC_MAT_LAMBERTIAN = 1, ORC_MAT_METAL = 2, ORC
 #define ORC_AXES_PACK(a, b, c, rev, rot) ((uint32_t)((a) | ((b) << 2) | ((c) << 4) | ((rev) << 6) | ((rot) << 7)))
 
 typedef struct orc_scene {
+    uint32_t        struct_size; /* unused here: keeps the layout identical to mirt_scene (one Python mirror serves both) */
     /* primitives, SoA, n_prims entries */
     uint32_t        n_prims;
     const uint32_t *prim_kind;   /* ORC_PRIM_*                                              */

@@ -15,10 +15,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmirt.so")
-SOURCES = ["mirt.hip"]
-DEPS = ["mirt.hip", "rt_kernels.h", "rt_device.h", "scene_host.h", os.path.join("..", "..", "include", "mirt.h")]
+SOURCES = ["mirt.hip", "mirt_multi.hip"]
+DEPS = ["mirt.hip", "mirt_multi.hip", "rt_kernels.h", "rt_device.h", "scene_host.h", os.path.join("..", "..", "include", "mirt.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-fPIC", "-shared",
-         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical"]
+         "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-ldl", "-pthread"]
 
 
 def stale() -> bool:

@@ -29,7 +29,7 @@ def axes_pack(a, b, c, rev, rot):
 class SceneStruct(C.Structure):
     """mirt_scene (and, layout-identical, the oracle's orc_scene)."""
     _fields_ = [
-        ("n_prims", C.c_uint32), ("prim_kind", u32p), ("prim_off", f32p), ("prim_geom", f32p),
+        ("struct_size", C.c_uint32), ("n_prims", C.c_uint32), ("prim_kind", u32p), ("prim_off", f32p), ("prim_geom", f32p),
         ("prim_axes", u32p), ("prim_rot", f32p), ("prim_mat", u32p),
         ("n_objects", C.c_uint32), ("obj_first", u32p), ("obj_count", u32p),
         ("n_mats", C.c_uint32), ("mat_kind", u32p), ("mat_albedo", f32p), ("mat_fuzz", f32p),
@@ -40,6 +40,10 @@ class SceneStruct(C.Structure):
         ("tex_rgba8", u8p), ("mat_texture", i32p),
     ]
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(SceneStruct)
+
 
 class CameraStruct(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("top_left", C.c_float * 3), ("horizontal", C.c_float * 3),
@@ -48,25 +52,51 @@ class CameraStruct(C.Structure):
 
 
 class RenderParams(C.Structure):
-    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp_begin", C.c_uint32),
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp_begin", C.c_uint32),
                 ("spp_count", C.c_uint32), ("max_depth", C.c_uint32), ("flags", C.c_uint32),
                 ("seed", C.c_uint64)]
 
+    def __init__(self, width=0, height=0, spp_begin=0, spp_count=0, max_depth=50, flags=0, seed=0):
+        super().__init__(C.sizeof(RenderParams), width, height, spp_begin, spp_count, max_depth, flags, seed)
+
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("depth_hist", C.c_uint64 * 64),
+    _fields_ = [("struct_size", C.c_uint32), ("rays", C.c_uint64), ("samples", C.c_uint64), ("depth_hist", C.c_uint64 * 64),
                 ("device_ms", C.c_double), ("extend_ms", C.c_double), ("bounce_launches", C.c_uint32),
                 ("batches", C.c_uint32), ("first_ms", C.c_double), ("extend_launches", C.c_uint32),
                 ("first_launches", C.c_uint32), ("depth_ms", C.c_double * 64)]
+
+    def __init__(self):
+        super().__init__()
+        self.struct_size = C.sizeof(Stats)
+
+
+ABI_VERSION = 2
+MULTI_MAX_DEVICES = 16
+REDUCE_AUTO, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
+
+
+class MultiInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_devices", C.c_uint32), ("reduce_kind", C.c_uint32), ("pad", C.c_uint32),
+                ("render_ms", C.c_double), ("reduce_ms", C.c_double), ("resolve_ms", C.c_double), ("reduce_bytes", C.c_uint64),
+                ("device", C.c_int32 * MULTI_MAX_DEVICES), ("spp_begin", C.c_uint32 * MULTI_MAX_DEVICES),
+                ("spp_count", C.c_uint32 * MULTI_MAX_DEVICES), ("device_ms", C.c_double * MULTI_MAX_DEVICES)]
+
+    def __init__(self):
+        super().__init__()
+        self.struct_size = C.sizeof(MultiInfo)
 
 
 HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", "<f4"), ("v", "<f4"),
                       ("mat", "<i4"), ("prim", "<i4")])
 
 EXPORTS = [
+    "mirt_abi_version", "mirt_check_abi",
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
     "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_render_device_noalloc", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
+    "mirt_multi_create", "mirt_multi_destroy", "mirt_multi_last_error", "mirt_multi_device_count", "mirt_multi_set_option",
+    "mirt_multi_upload_scene", "mirt_multi_set_camera", "mirt_multi_spp_range", "mirt_multi_render",
     "mirt_camera_rays", "mirt_philox_batch", "mirt_arith_batch", "mirt_tex_sample_batch", "mirt_write_ppm", "mirt_write_image",
 ]
 
@@ -88,6 +118,8 @@ def load():
                         "(the path tracer has no CPU fallback)")
     lib = C.CDLL(path)
     vp = C.c_void_p
+    lib.mirt_abi_version.argtypes = []
+    lib.mirt_check_abi.argtypes = [C.c_uint32] + [C.c_size_t] * 5
     lib.mirt_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.mirt_destroy.argtypes = [vp]; lib.mirt_destroy.restype = None
     lib.mirt_last_error.argtypes = [vp]; lib.mirt_last_error.restype = C.c_char_p
@@ -98,6 +130,15 @@ def load():
     lib.mirt_build_bvh.argtypes = [C.POINTER(SceneStruct), C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.mirt_render_device.argtypes = [vp, C.POINTER(RenderParams), vp, vp, C.POINTER(Stats)]
     lib.mirt_render_device_noalloc.argtypes = [vp, C.POINTER(RenderParams), vp, vp]
+    lib.mirt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.mirt_multi_destroy.argtypes = [vp]; lib.mirt_multi_destroy.restype = None
+    lib.mirt_multi_last_error.argtypes = [vp]; lib.mirt_multi_last_error.restype = C.c_char_p
+    lib.mirt_multi_device_count.argtypes = [vp]
+    lib.mirt_multi_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.mirt_multi_upload_scene.argtypes = [vp, C.POINTER(SceneStruct)]
+    lib.mirt_multi_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
+    lib.mirt_multi_spp_range.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]; lib.mirt_multi_spp_range.restype = None
+    lib.mirt_multi_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats), C.POINTER(MultiInfo)]
     lib.mirt_resolve_device.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.mirt_render.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
     lib.mirt_render_progressive.argtypes = [vp, C.POINTER(RenderParams), vp, vp, vp, C.POINTER(Stats)]
@@ -112,8 +153,12 @@ def load():
     lib.mirt_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]
     lib.mirt_write_image.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.c_uint32, vp, vp]
     for name in EXPORTS:
-        if name not in ("mirt_destroy", "mirt_last_error"):
+        if name not in ("mirt_destroy", "mirt_last_error", "mirt_abi_version", "mirt_multi_destroy", "mirt_multi_last_error", "mirt_multi_spp_range"):
             getattr(lib, name).restype = C.c_int
+    lib.mirt_abi_version.restype = C.c_uint32
+    # the ABI guard of include/mirt.h: this mirror's struct sizes against the library's, once at load
+    if lib.mirt_check_abi(ABI_VERSION, C.sizeof(SceneStruct), C.sizeof(CameraStruct), HIT_DTYPE.itemsize, C.sizeof(RenderParams), C.sizeof(Stats)) != 0:
+        raise MirtError("capi.py and libmirt.so disagree about the ABI: " + lib.mirt_last_error(None).decode())
     _lib = lib
     return lib
 
@@ -268,6 +313,63 @@ class Context:
         self._ck(self.lib.mirt_arith_batch(self.h, op, _ptr(x), _ptr(yy) if yy is not None else None, x.shape[0], _ptr(out)),
                  "mirt_arith_batch")
         return out
+
+
+class MultiContext:
+    """mirt_multi: one render sharded by samples per pixel over several GPUs of this process (a device may be listed
+    twice with the peer reduce, which is how a one-GPU box exercises the path)."""
+
+    def __init__(self, devices):
+        self.lib = load()
+        ids = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.lib.mirt_multi_create(ids, len(devices), C.byref(h))
+        if rc != 0:
+            raise MirtError(f"mirt_multi_create failed ({rc}): {self.lib.mirt_multi_last_error(None).decode()}")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mirt_multi_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MirtError(f"{what} failed ({rc}): {self.lib.mirt_multi_last_error(self.h).decode()}")
+
+    def set_option(self, name, value):
+        self._ck(self.lib.mirt_multi_set_option(self.h, name.encode(), int(value)), "mirt_multi_set_option")
+
+    def upload_scene(self, scene):
+        st = scene.as_struct()
+        self._ck(self.lib.mirt_multi_upload_scene(self.h, C.byref(st)), "mirt_multi_upload_scene")
+
+    def set_camera(self, cam):
+        self._ck(self.lib.mirt_multi_set_camera(self.h, C.byref(cam)), "mirt_multi_set_camera")
+
+    def render(self, width, height, spp, max_depth=50, seed=0x5EED, flags=FLAG_ACCEL_AUTO, spp_begin=0, want=("sum", "pixels", "rgba8")):
+        p = RenderParams(width, height, spp_begin, spp, max_depth, flags, seed)
+        s = np.empty((height, width, 3), np.float32) if "sum" in want else None
+        px = np.empty((height, width, 3), np.float32) if "pixels" in want else None
+        rg = np.empty((height, width, 4), np.uint8) if "rgba8" in want else None
+        st, info = Stats(), MultiInfo()
+        self._ck(self.lib.mirt_multi_render(self.h, C.byref(p), _ptr(s) if s is not None else None, _ptr(px) if px is not None else None,
+                                            _ptr(rg) if rg is not None else None, C.byref(st), C.byref(info)), "mirt_multi_render")
+        return {"sum": s, "pixels": px, "rgba8": rg, "stats": st, "info": info}
+
+
+def multi_spp_range(rank, world, spp_begin, spp_count):
+    b, n = C.c_uint32(), C.c_uint32()
+    load().mirt_multi_spp_range(rank, world, spp_begin, spp_count, C.byref(b), C.byref(n))
+    return b.value, n.value
 
 
 def build_bvh(scene):

@@ -104,6 +104,33 @@ extern "C" int mirt_device_count(void)
     return n;
 }
 
+extern "C" uint32_t mirt_abi_version(void) { return MIRT_ABI_VERSION; }
+
+extern "C" int mirt_check_abi(uint32_t version, size_t sizeof_scene, size_t sizeof_camera, size_t sizeof_hit, size_t sizeof_render_params, size_t sizeof_stats)
+{
+    const bool ok = version == MIRT_ABI_VERSION && sizeof_scene == sizeof(mirt_scene) && sizeof_camera == sizeof(mirt_camera) && sizeof_hit == sizeof(mirt_hit) &&
+                    sizeof_render_params == sizeof(mirt_render_params) && sizeof_stats == sizeof(mirt_stats);
+    if (!ok) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "mirt_check_abi: caller built against ABI %u (scene %zu, camera %zu, hit %zu, params %zu, stats %zu bytes), library is ABI %u (%zu, %zu, %zu, %zu, %zu)",
+                 version, sizeof_scene, sizeof_camera, sizeof_hit, sizeof_render_params, sizeof_stats, (unsigned)MIRT_ABI_VERSION, sizeof(mirt_scene), sizeof(mirt_camera),
+                 sizeof(mirt_hit), sizeof(mirt_render_params), sizeof(mirt_stats));
+        g_create_error = buf;                           // mirt_last_error(NULL)
+    }
+    return ok ? MIRT_OK : MIRT_ERR_ARG;
+}
+
+// struct_size of the in/out structs (include/mirt.h, "ABI guard"): a host compiled against another revision of the
+// header gets MIRT_ERR_ARG before anything is read or written through the pointer.
+static int size_mismatch(mirt_ctx *c, const char *what, uint32_t got, size_t want)
+{
+    const std::string msg = std::string(what) + ".struct_size is " + std::to_string(got) + ", this library was built with " + std::to_string(want) +
+                            " (set it to sizeof, and rebuild the host against this include/mirt.h)";
+    if (c) c->err = msg; else g_create_error = msg;
+    return MIRT_ERR_ARG;
+}
+#define CHECK_SIZE(ctx, ptr, type) do { if ((ptr) && (ptr)->struct_size != sizeof(type)) return size_mismatch(ctx, #type, (ptr)->struct_size, sizeof(type)); } while (0)
+
 extern "C" int mirt_create(int device_id, mirt_ctx **out)
 {
     if (!out) { g_create_error = "mirt_create: out is NULL"; return MIRT_ERR_ARG; }
@@ -173,6 +200,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
 extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
 {
     if (!c || !s) return MIRT_ERR_ARG;
+    CHECK_SIZE(c, s, mirt_scene);
     HIPCHK(c, hipSetDevice(c->device));
     std::string why = host::validate(*s);
     if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
@@ -180,6 +208,10 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     why = host::prepare_tree(*s, tree);
     if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
     if (tree.depth > 60) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: BVH deeper than 60 levels");
+    // From here on the context's buffers are rewritten in place (DevBuf::ensure frees before it allocates): until every
+    // allocation and copy has succeeded the context has no scene, so a failed re-upload cannot leave render or batch
+    // calls with pointers to freed buffers.
+    c->have_scene = false;
 
     std::vector<PrimRec> prims(s->n_prims);
     for (uint32_t p = 0; p < s->n_prims; ++p) {
@@ -316,6 +348,7 @@ extern "C" int mirt_build_bvh(const mirt_scene *scene, uint32_t capacity_nodes, 
                               int32_t *node_left, int32_t *node_right, int32_t *root, uint32_t *n_nodes, uint32_t *depth)
 {
     if (!scene || !node_min || !node_max || !node_left || !node_right || !root || !n_nodes) return MIRT_ERR_ARG;
+    CHECK_SIZE(nullptr, scene, mirt_scene);
     mirt_scene s = *scene; s.n_nodes = 0;
     if (!host::validate(s).empty()) return MIRT_ERR_ARG;
     host::Tree tree;
@@ -540,6 +573,7 @@ static int check_render_args(mirt_ctx *c, const mirt_render_params *p)
 extern "C" int mirt_render_device_noalloc(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream)
 {
     if (!c || !p || !d_sum) return MIRT_ERR_ARG;
+    CHECK_SIZE(c, p, mirt_render_params);
     int rc = check_render_args(c, p);
     if (rc) return rc;
     if (c->engine != 1) return fail(c, MIRT_ERR_STATE, "mirt_render_device_noalloc: the persistent engine only (option engine=1)");
@@ -559,13 +593,14 @@ extern "C" int mirt_render_device_noalloc(mirt_ctx *c, const mirt_render_params 
 extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, float *d_sum, void *stream, mirt_stats *stats)
 {
     if (!c || !p || !d_sum) return MIRT_ERR_ARG;
+    CHECK_SIZE(c, p, mirt_render_params); CHECK_SIZE(c, stats, mirt_stats);
     int rc_args = check_render_args(c, p);
     if (rc_args) return rc_args;
     const uint64_t npix_total = (uint64_t)p->width * p->height;
     const bool one_spp = p->flags & MIRT_FLAG_ONE_SPP;
     const uint32_t spp_count = one_spp ? 1u : p->spp_count;
     const uint32_t spp_begin = one_spp ? 0u : p->spp_begin;
-    if (stats) memset(stats, 0, sizeof *stats);
+    if (stats) { memset(stats, 0, sizeof *stats); stats->struct_size = (uint32_t)sizeof *stats; }
     if (spp_count == 0) return MIRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -687,6 +722,7 @@ extern "C" int mirt_resolve_device(mirt_ctx *c, const float *d_sum, uint32_t w, 
 extern "C" int mirt_render(mirt_ctx *c, const mirt_render_params *p, float *h_sum, float *h_pixels, uint8_t *h_rgba8, mirt_stats *stats)
 {
     if (!c || !p) return MIRT_ERR_ARG;
+    CHECK_SIZE(c, p, mirt_render_params); CHECK_SIZE(c, stats, mirt_stats);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npix = (size_t)p->width * p->height;
     if (!npix) return fail(c, MIRT_ERR_ARG, "mirt_render: empty image");
@@ -710,6 +746,7 @@ extern "C" int mirt_render(mirt_ctx *c, const mirt_render_params *p, float *h_su
 extern "C" int mirt_render_progressive(mirt_ctx *c, const mirt_render_params *p, float *h_sum, float *h_pixels, uint8_t *h_rgba8, mirt_stats *stats)
 {
     if (!c || !p) return MIRT_ERR_ARG;
+    CHECK_SIZE(c, p, mirt_render_params); CHECK_SIZE(c, stats, mirt_stats);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t npix = (size_t)p->width * p->height;
     if (!npix) return fail(c, MIRT_ERR_ARG, "mirt_render_progressive: empty image");
@@ -796,6 +833,9 @@ extern "C" int mirt_world_hit_batch(mirt_ctx *c, const float *org, const float *
     NEED(dorg && ddir && dout);
     dim3 g((uint32_t)std::min<size_t>((nray + MIRT_BLOCK - 1) / MIRT_BLOCK, (size_t)c->n_cu * 16)), b(MIRT_BLOCK);
     const int mode = accel_mode(c, flags);
+    // the list and near-first walks assume t_min > 0 (the sphere "behind the origin" cull, the next-float-up of slab_hit,
+    // the estimated-root band); the render path always passes 0.001.  The reference-order walk (no accel flag) takes any t_min.
+    if (mode != 1 && !(t_min > 0.0f)) return fail(c, MIRT_ERR_ARG, "mirt_world_hit_batch: t_min must be > 0 with MIRT_FLAG_ACCEL_LIST/_AUTO/_ORDERED (pass no accel flag for t_min <= 0)");
     const bool pl = c->prims_in_lds;
     const uint32_t lds = mode == 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
     SceneDev sd = mode == 2 ? c->sc2 : c->sc;

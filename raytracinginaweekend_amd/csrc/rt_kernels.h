@@ -548,11 +548,13 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
             acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
         }
         const unsigned long long am = __ballot(acc);
-        const uint32_t bits = (uint32_t)(am >> (rank << lg)) & ((1u << G) - 1u);   // this lane's G helpers, lowest = earliest iteration
+        // a lane that is not pending can have rank == n, and n * G can be 64: its shift count is clamped (a 64-bit shift by 64 is undefined)
+        const uint32_t sh = pending ? (rank << lg) : 0u;
+        const uint32_t bits = (uint32_t)(am >> sh) & ((1u << G) - 1u);             // this lane's G helpers, lowest = earliest iteration
         const bool got = pending & (bits != 0u);
         // byte address of the helper lane for ds_bpermute (what __shfl computes, minus its width arithmetic); the find-first
         // of an empty set is used only under `got`
-        const int src4 = (int)((got ? (rank << lg) + (uint32_t)__builtin_ctz(bits) : lane) << 2);
+        const int src4 = (int)((got ? sh + (uint32_t)__builtin_ctz(bits) : lane) << 2);
         next_it += (pending & !got) ? G : 0u;
         const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[0]), c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[1]),
                        c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[2]);

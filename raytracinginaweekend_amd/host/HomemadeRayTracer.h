@@ -1,6 +1,7 @@
 // HomemadeRayTracer.h -- the seam (reference HomemadeRayTracer.h:11-33).  TraceRay flattens the world,
 // uploads it through the C ABI of include/mirt.h and renders on the MI355X; there is no CPU path.
 #pragma once
+#include <vector>
 #include "Vec3.h"
 #include "../../include/mirt.h"
 
@@ -31,6 +32,12 @@ public:
 	void SetMaxDepth(UINT32 depth) { m_maxDepth = depth; }
 	void SetSeed(UINT64 seed) { m_seed = seed; }
 	void SetDevice(int device) { m_device = device; }
+	// Several GPUs of the node for TraceRay: the samples of every pixel are split over them (mirt_multi, include/mirt.h),
+	// device ids[0] gathers and resolves.  SetDeviceCount(n) = devices 0..n-1.  Takes effect at the next TraceRay;
+	// TraceRayProgressive and the 1-SPP preview stay on one device.
+	void SetDevices(const std::vector<int> &ids);
+	void SetDeviceCount(int n);
+	const mirt_multi_info &LastMultiInfo() const { return m_multiInfo; }
 	void Enable1SPP(BOOL on) { m_enable1SPP = on; }
 	void EnableNormalDisplay(BOOL on) { m_enableNormalDisplay = on; }
 	const mirt_stats &LastStats() const { return m_stats; }
@@ -45,6 +52,13 @@ private:
 	int            m_device{ 0 };
 	mirt_ctx      *m_ctx{ nullptr };
 	const World   *m_uploadedWorld{ nullptr };
+	UINT64         m_uploadedGeneration{ 0 };
 	mirt_stats     m_stats{};
+	std::vector<int> m_devices;                      // empty: one device (m_device) through m_ctx
+	mirt_multi    *m_multi{ nullptr };
+	const World   *m_multiWorld{ nullptr };           // what m_multi's devices hold (tracked apart from m_ctx's copy)
+	UINT64         m_multiGeneration{ 0 };
+	mirt_multi_info m_multiInfo{};
+	void ReleaseMulti();
 	void Prepare(const SimpleCamera *camera);        // context, scene upload (once per world), camera
 };

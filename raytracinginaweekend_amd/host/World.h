@@ -37,7 +37,11 @@ public:
 	LightSources        *GetLightSources() const { return m_lightSources; }
 	size_t               GetObjectsCount() const { return m_objectsCount; }
 	// for scene code that builds its own world: hand over the tree and the lights
-	void Adopt(SimpleObjectBVHNode *tree, LightSources *lights, size_t objectCount) { m_objectBVHTree = tree; m_lightSources = lights; m_objectsCount = objectCount; }
+	void Adopt(SimpleObjectBVHNode *tree, LightSources *lights, size_t objectCount) { m_objectBVHTree = tree; m_lightSources = lights; m_objectsCount = objectCount; ++m_generation; }
+	// Bumped whenever the scene changes (ConstructWorld, DeconstructWorld, Adopt); HomemadeRayTracer re-flattens and
+	// re-uploads when it differs from the generation it uploaded.  Scene code that edits objects in place calls Touch().
+	UINT64 Generation() const { return m_generation; }
+	void   Touch() { ++m_generation; if (m_queryCtx) { mirt_destroy(m_queryCtx); m_queryCtx = nullptr; } }
 
 	void Flatten(FlatScene &out) const;
 
@@ -55,4 +59,5 @@ private:
 	LightSources        *m_lightSources{ nullptr };
 	mutable mirt_ctx    *m_queryCtx{ nullptr };
 	int                  m_queryDevice{ 0 };
+	UINT64               m_generation{ 0 };
 };

@@ -132,6 +132,7 @@ void FlatScene::EndObject()
 mirt_scene FlatScene::View() const
 {
 	mirt_scene s{};
+	s.struct_size = (uint32_t)sizeof s;
 	s.n_prims = (uint32_t)prim_kind.size(); s.prim_kind = prim_kind.data(); s.prim_off = prim_off.data(); s.prim_geom = prim_geom.data();
 	s.prim_axes = prim_axes.data(); s.prim_rot = prim_rot.data(); s.prim_mat = prim_mat.data();
 	s.n_objects = (uint32_t)obj_first.size(); s.obj_first = obj_first.data(); s.obj_count = obj_count.data();
@@ -507,6 +508,7 @@ LightSources::LightSources(World *world, std::vector<Object *> &objects, const V
 // =========================================================================================== World
 void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // World.cpp:15-110
 {
+	++m_generation;
 	m_resources = new Resources();
 	m_resources->Load();
 	auto mat = [&](MaterialUniqueID id) { return m_resources->GetTheMaterial(id); };
@@ -570,6 +572,7 @@ void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // Worl
 }
 void World::DeconstructWorld()
 {
+	++m_generation;                                   // tracers that flattened this world must do it again
 	if (m_queryCtx) { mirt_destroy(m_queryCtx); m_queryCtx = nullptr; }
 	delete m_objectBVHTree; m_objectBVHTree = nullptr; m_objects.clear();
 	delete m_lightSources; m_lightSources = nullptr;
@@ -588,6 +591,7 @@ BOOL World::ClosestHit(const Ray &r, float tMin, float tMax, Vec3 &position) con
 {
 	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_queryCtx)); };
 	if (!m_queryCtx) {
+		if (MIRT_CHECK_ABI() != MIRT_OK) throw std::runtime_error(std::string("ABI mismatch: ") + mirt_last_error(nullptr));
 		check(mirt_create(m_queryDevice, &m_queryCtx), "mirt_create");
 		FlatScene flat;
 		Flatten(flat);
@@ -772,8 +776,25 @@ void PPMImageMaker::OutputRGBA8ToBinaryFile(const char *fileName, UINT32 w, UINT
 }
 
 // =========================================================================================== HomemadeRayTracer
+// ABI guard (include/mirt.h): this layer's struct sizes against the loaded libmirt.so, once at load
+static const bool g_abi_ok = MIRT_CHECK_ABI() == MIRT_OK;
 HomemadeRayTracer::HomemadeRayTracer(InputListener *inputListener, OutputImage *, const World *world) : m_inputListener(inputListener), m_world(world) {}
-HomemadeRayTracer::~HomemadeRayTracer() { if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; }
+HomemadeRayTracer::~HomemadeRayTracer() { if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; ReleaseMulti(); }
+void HomemadeRayTracer::ReleaseMulti() { if (m_multi) mirt_multi_destroy(m_multi); m_multi = nullptr; }
+void HomemadeRayTracer::SetDevices(const std::vector<int> &ids)
+{
+	if (ids.size() > MIRT_MULTI_MAX_DEVICES) throw std::invalid_argument("HomemadeRayTracer::SetDevices: too many devices");
+	ReleaseMulti();
+	m_devices = ids.size() > 1 ? ids : std::vector<int>();
+	if (ids.size() == 1) SetDevice(ids[0]);
+}
+void HomemadeRayTracer::SetDeviceCount(int n)
+{
+	if (n < 1 || n > mirt_device_count()) throw std::invalid_argument("HomemadeRayTracer::SetDeviceCount: the node has " + std::to_string(mirt_device_count()) + " GPU(s)");
+	std::vector<int> ids(n);
+	for (int i = 0; i < n; ++i) ids[i] = i;
+	SetDevices(ids);
+}
 void HomemadeRayTracer::OnInit()                                          // HomemadeRayTracer.cpp:36-43
 {
 	cout << "[HomemadeRayTracer] Init" << endl;
@@ -787,7 +808,7 @@ void HomemadeRayTracer::OnUpdate(const SimpleCamera *camera, OutputImage *image)
 	if (m_inputListener->WhenReleaseKey('N')) { m_enableNormalDisplay = !m_enableNormalDisplay; cout << "[HomemadeRayTracer][NormalDisplay] " << (m_enableNormalDisplay ? "Enabled" : "Disabled") << endl; }
 	if (m_inputListener->WhenReleaseKey('M')) { m_enable1SPP = !m_enable1SPP; cout << "[HomemadeRayTracer][1SPP] " << (m_enable1SPP ? "Enabled" : "Disabled") << endl; }
 }
-void HomemadeRayTracer::OnDestroy() { cout << "[HomemadeRayTracer] Destroy" << endl; if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; m_uploadedWorld = nullptr; }
+void HomemadeRayTracer::OnDestroy() { cout << "[HomemadeRayTracer] Destroy" << endl; if (m_ctx) mirt_destroy(m_ctx); m_ctx = nullptr; m_uploadedWorld = nullptr; ReleaseMulti(); }
 void HomemadeRayTracer::HelpInfo()
 {
 	cout << "=============HomemadeRayTracer (MI355X)============" << endl
@@ -798,13 +819,17 @@ void HomemadeRayTracer::HelpInfo()
 void HomemadeRayTracer::Prepare(const SimpleCamera *camera)
 {
 	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_ctx)); };
-	if (!m_ctx) check(mirt_create(m_device, &m_ctx), "mirt_create");
-	if (m_uploadedWorld != m_world) {
+	if (!g_abi_ok) throw std::runtime_error(std::string("libmirt_host.so and libmirt.so were built from different revisions of include/mirt.h: ") + mirt_last_error(nullptr));
+	const bool fresh = !m_ctx;
+	if (fresh) check(mirt_create(m_device, &m_ctx), "mirt_create");
+	// The reference reads the live pointer graph on every TraceRay; here the flattened copy on the device is kept until the
+	// world says it changed (ConstructWorld / DeconstructWorld / Adopt / Touch bump its generation).
+	if (fresh || m_uploadedWorld != m_world || m_uploadedGeneration != m_world->Generation()) {
 		FlatScene flat;
 		m_world->Flatten(flat);
 		mirt_scene view = flat.View();
 		check(mirt_upload_scene(m_ctx, &view), "mirt_upload_scene");
-		m_uploadedWorld = m_world;
+		m_uploadedWorld = m_world; m_uploadedGeneration = m_world->Generation();
 	}
 	mirt_camera cam; camera->Export(cam);
 	check(mirt_set_camera(m_ctx, &cam), "mirt_set_camera");
@@ -814,6 +839,7 @@ void HomemadeRayTracer::TraceRayProgressive(const SimpleCamera *camera, OutputIm
 	if (!camera || !image || !m_world) throw std::invalid_argument("HomemadeRayTracer::TraceRayProgressive: null argument");
 	Prepare(camera);
 	mirt_render_params p{};
+	p.struct_size = (uint32_t)sizeof p; m_stats.struct_size = (uint32_t)sizeof m_stats;
 	p.width = image->m_width; p.height = image->m_height; p.spp_begin = firstSample; p.spp_count = sampleCount; p.max_depth = m_maxDepth; p.seed = m_seed;
 	p.flags = MIRT_FLAG_ACCEL_AUTO | (m_enableNormalDisplay ? MIRT_FLAG_NORMAL_DISPLAY : 0u);
 	if (mirt_render_progressive(m_ctx, &p, nullptr, nullptr, image->m_data, &m_stats) != MIRT_OK)
@@ -826,11 +852,31 @@ void HomemadeRayTracer::TraceRay(const SimpleCamera *camera, OutputImage *image)
 	cout << "[HomemadeRayTracer] TraceRay ..." << endl;
 	cout << "[HomemadeRayTracer] SPP: " << (m_enable1SPP ? 1u : m_spp) << endl;
 	auto check = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_last_error(m_ctx)); };
-	Prepare(camera);
 	mirt_render_params p{};
+	p.struct_size = (uint32_t)sizeof p; m_stats.struct_size = (uint32_t)sizeof m_stats;
 	p.width = image->m_width; p.height = image->m_height; p.spp_begin = 0; p.spp_count = m_spp; p.max_depth = m_maxDepth; p.seed = m_seed;
 	p.flags = MIRT_FLAG_ACCEL_AUTO | (m_enable1SPP ? MIRT_FLAG_ONE_SPP : 0u) | (m_enableNormalDisplay ? MIRT_FLAG_NORMAL_DISPLAY : 0u);
-	check(mirt_render(m_ctx, &p, nullptr, nullptr, image->m_data, &m_stats), "mirt_render");   // device resolve == OutputImage::Render
+	if (m_devices.size() > 1 && !m_enable1SPP) {
+		// the samples of every pixel split over the GPUs of the node, summed onto m_devices[0] (mirt_multi)
+		auto mcheck = [&](int rc, const char *what) { if (rc != MIRT_OK) throw std::runtime_error(std::string(what) + ": " + mirt_multi_last_error(m_multi)); };
+		if (!g_abi_ok) throw std::runtime_error(std::string("ABI mismatch between libmirt_host.so and libmirt.so: ") + mirt_last_error(nullptr));
+		const bool fresh = !m_multi;
+		if (fresh) mcheck(mirt_multi_create(m_devices.data(), (int)m_devices.size(), &m_multi), "mirt_multi_create");
+		if (fresh || m_multiWorld != m_world || m_multiGeneration != m_world->Generation()) {
+			FlatScene flat;
+			m_world->Flatten(flat);
+			mirt_scene view = flat.View();
+			mcheck(mirt_multi_upload_scene(m_multi, &view), "mirt_multi_upload_scene");
+			m_multiWorld = m_world; m_multiGeneration = m_world->Generation();
+		}
+		mirt_camera cam; camera->Export(cam);
+		mcheck(mirt_multi_set_camera(m_multi, &cam), "mirt_multi_set_camera");
+		m_multiInfo.struct_size = (uint32_t)sizeof m_multiInfo;
+		mcheck(mirt_multi_render(m_multi, &p, nullptr, nullptr, image->m_data, &m_stats, &m_multiInfo), "mirt_multi_render");
+	} else {
+		Prepare(camera);
+		check(mirt_render(m_ctx, &p, nullptr, nullptr, image->m_data, &m_stats), "mirt_render");   // device resolve == OutputImage::Render
+	}
 	image->m_isDirty = TRUE;
 	cout << "[HomemadeRayTracer] Done (" << m_stats.rays << " rays, " << m_stats.device_ms << " ms on the GPU)" << endl;
 }
@@ -903,6 +949,53 @@ int mirt_host_render(int world_id, uint32_t w, uint32_t h, uint32_t spp, uint32_
 		rt.TraceRay(&camera, &image);
 		if (rgba8_out) memcpy(rgba8_out, image.m_data, image.m_dataSizeInByte);
 		if (ppm_dir) { image.m_outputDir = ppm_dir; image.Output(); }
+		rt.OnDestroy();
+		world.DeconstructWorld();
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// One World object and one tracer, two scenes in a row: ConstructWorld(a), TraceRay, DeconstructWorld, ConstructWorld(b),
+// TraceRay.  The second image must be world b's (the tracer's flattened copy follows World::Generation()).
+int mirt_host_render_rebuilt(int world_a, int world_b, uint32_t w, uint32_t h, uint32_t spp, uint64_t scene_seed, uint64_t seed,
+                             uint8_t *rgba8_first, uint8_t *rgba8_second, char *err, size_t errlen)
+{
+	try {
+		InputListener input; OutputImage image(w, h, "OutputImage"); World world;
+		SimpleCamera camera(&world, &input, image.m_aspectRatio);
+		HomemadeRayTracer rt(&input, &image, &world);
+		rt.OnInit();
+		rt.SetSamplesPerPixel(spp); rt.SetSeed(seed); rt.Enable1SPP(FALSE);
+		const int ids[2] = { world_a, world_b };
+		uint8_t *outs[2] = { rgba8_first, rgba8_second };
+		for (int k = 0; k < 2; ++k) {
+			if (k) world.DeconstructWorld();
+			Randomizer::Seed(scene_seed);
+			world.ConstructWorld((WorldID)ids[k], &camera);
+			rt.TraceRay(&camera, &image);
+			if (outs[k]) memcpy(outs[k], image.m_data, image.m_dataSizeInByte);
+		}
+		rt.OnDestroy();
+		world.DeconstructWorld();
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
+// TraceRay over several devices (HomemadeRayTracer::SetDevices): image bytes + what mirt_multi reports
+int mirt_host_render_devices(int world_id, uint32_t w, uint32_t h, uint32_t spp, uint64_t scene_seed, uint64_t seed, const int *devices, int n_devices,
+                             uint8_t *rgba8_out, mirt_multi_info *info_out, uint64_t *rays_out, char *err, size_t errlen)
+{
+	try {
+		InputListener input; OutputImage image(w, h, "OutputImage"); World world;
+		Randomizer::Seed(scene_seed);
+		SimpleCamera camera(&world, &input, image.m_aspectRatio);
+		world.ConstructWorld((WorldID)world_id, &camera);
+		HomemadeRayTracer rt(&input, &image, &world);
+		rt.OnInit();
+		rt.SetSamplesPerPixel(spp); rt.SetSeed(seed); rt.Enable1SPP(FALSE);
+		rt.SetDevices(std::vector<int>(devices, devices + n_devices));
+		rt.TraceRay(&camera, &image);
+		if (rgba8_out) memcpy(rgba8_out, image.m_data, image.m_dataSizeInByte);
+		if (info_out) *info_out = rt.LastMultiInfo();
+		if (rays_out) *rays_out = rt.LastStats().rays;
 		rt.OnDestroy();
 		world.DeconstructWorld();
 		return 0;

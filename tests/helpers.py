@@ -75,7 +75,7 @@ def synthetic_texture(w, h, seed, kind="checker"):
     return img
 
 
-def write_tga(path, rgba, kind="rgb24", rle=False, origin="ll", id_bytes=b""):
+def write_tga(path, rgba, kind="rgb24", rle=False, origin="ll", id_bytes=b"", cmap_origin=0):
     """Writes `rgba` ((h, w, 4) uint8, row 0 = top) as a TGA file: kind rgb24 | rgb32 | gray | cmap24 | cmap32,
     optionally run-length encoded, with the first stored pixel at the given corner (ll, ul, lr, ur).
     Returns the RGBA image a decoder must produce (alpha 255 unless the file stores it; grey replicates)."""
@@ -104,7 +104,7 @@ def write_tga(path, rgba, kind="rgb24", rle=False, origin="ll", id_bytes=b""):
         pal = np.array([[(i // 16) * 64 + 17, ((i // 4) % 4) * 64 + 29, (i % 4) * 64 + 5, 100 + i] for i in range(64)], np.uint8)   # R,G,B,A
         palette = pal[:, [2, 1, 0, 3]][:, :cbytes].tobytes()
         cmap_len, cmap_depth = 64, cbytes * 8
-        px = idx.reshape(-1, 1)
+        px = (idx + cmap_origin).astype(np.uint8).reshape(-1, 1)                       # stored index = palette entry + first-entry index
         full = pal[idx]
         full = full[:, ::-1] if origin[1] == "r" else full
         full = full[::-1] if origin[0] == "l" else full
@@ -129,7 +129,7 @@ def write_tga(path, rgba, kind="rgb24", rle=False, origin="ll", id_bytes=b""):
         data = bytes(out); itype += 8
     else:
         data = px.tobytes()
-    head = bytes([len(id_bytes), 1 if palette else 0, itype, 0, 0, cmap_len & 255, cmap_len >> 8, cmap_depth, 0, 0, 0, 0,
+    head = bytes([len(id_bytes), 1 if palette else 0, itype, cmap_origin & 255, cmap_origin >> 8, cmap_len & 255, cmap_len >> 8, cmap_depth, 0, 0, 0, 0,
                   w & 255, w >> 8, h & 255, h >> 8, bpp * 8, desc | (8 if kind == "rgb32" else 0)])
     with open(path, "wb") as f:
         f.write(head + id_bytes + palette + data)

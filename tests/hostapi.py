@@ -81,6 +81,33 @@ def render(world_id, w, h, spp, depth=50, scene_seed=1, seed=0x5EED, one_spp=Fal
     return out
 
 
+def render_rebuilt(world_a, world_b, w, h, spp, scene_seed=1, seed=0x5EED):
+    """One World + one HomemadeRayTracer: world_a rendered, the world deconstructed and rebuilt as world_b, rendered again."""
+    L = lib()
+    L.mirt_host_render_rebuilt.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t]
+    L.mirt_host_render_rebuilt.restype = C.c_int
+    a, b = np.zeros((h, w, 4), np.uint8), np.zeros((h, w, 4), np.uint8)
+    err = C.create_string_buffer(512)
+    if L.mirt_host_render_rebuilt(world_a, world_b, w, h, spp, scene_seed, seed, a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), err, 512) != 0:
+        raise RuntimeError(err.value.decode())
+    return a, b
+
+
+def render_devices(world_id, w, h, spp, devices, scene_seed=1, seed=0x5EED):
+    """HomemadeRayTracer::SetDevices(devices) + TraceRay -> (rgba8, MultiInfo, rays)."""
+    L = lib()
+    L.mirt_host_render_devices.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_int), C.c_int, C.c_void_p,
+                                           C.POINTER(capi.MultiInfo), C.POINTER(C.c_uint64), C.c_char_p, C.c_size_t]
+    L.mirt_host_render_devices.restype = C.c_int
+    out = np.zeros((h, w, 4), np.uint8)
+    info, rays = capi.MultiInfo(), C.c_uint64()
+    err = C.create_string_buffer(512)
+    ids = (C.c_int * len(devices))(*devices)
+    if L.mirt_host_render_devices(world_id, w, h, spp, scene_seed, seed, ids, len(devices), out.ctypes.data_as(C.c_void_p), C.byref(info), C.byref(rays), err, 512) != 0:
+        raise RuntimeError(err.value.decode())
+    return out, info, rays.value
+
+
 def decode_tga(path, cap=1 << 24):
     L = lib()
     L.mirt_host_decode_tga.argtypes = [C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]

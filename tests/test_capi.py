@@ -48,6 +48,27 @@ def test_struct_layouts_match_the_header(tmp_path):
     assert out2 == [out[0], out[1], out[2], out[5]]
 
 
+def test_abi_guard_rejects_a_host_built_against_another_header():
+    """include/mirt.h "ABI guard": a host with a shorter mirt_stats (the abort of round 1: a stale libmirt_host.so handed a
+    grown libmirt.so a 512-byte-shorter struct on its stack) gets an error code at load and per call, never a write."""
+    lib = capi.load()
+    sizes = [C.sizeof(capi.SceneStruct), C.sizeof(capi.CameraStruct), capi.HIT_DTYPE.itemsize, C.sizeof(capi.RenderParams), C.sizeof(capi.Stats)]
+    assert lib.mirt_abi_version() == capi.ABI_VERSION and lib.mirt_check_abi(capi.ABI_VERSION, *sizes) == 0
+    assert lib.mirt_check_abi(capi.ABI_VERSION - 1, *sizes) == -1
+    short = sizes[:4] + [sizes[4] - 512]
+    assert lib.mirt_check_abi(capi.ABI_VERSION, *short) == -1
+    assert b"stats" in lib.mirt_last_error(None)
+    # per call, host-only entry point: a scene struct that claims another size is refused before any pointer in it is followed
+    s, _ = scene.cornell_box(1.0)
+    st = s.as_struct()
+    st.struct_size -= 8
+    out = np.zeros(64, np.float32)
+    o = lambda: out.ctypes.data_as(C.c_void_p)
+    root, n = C.c_int32(), C.c_uint32()
+    assert lib.mirt_build_bvh(C.byref(st), 8, o(), o(), o(), o(), C.byref(root), C.byref(n), None) == -1
+    assert b"struct_size" in lib.mirt_last_error(None) and not out.any()
+
+
 @pytest.mark.skipif(capi.load().mirt_device_count() > 0, reason="a GPU is present")
 def test_no_gpu_means_a_loud_failure_not_a_fallback():
     with pytest.raises(capi.MirtError, match="no HIP device"):

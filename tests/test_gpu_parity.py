@@ -275,6 +275,19 @@ def test_errors(gpu):
     s._arrays = None
     with pytest.raises(capi.MirtError, match="material index"):
         gpu.upload_scene(s)
+    # ABI guard: structs that claim another size are refused with an error code, and a short mirt_stats is never written
+    import ctypes as C
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    p = capi.RenderParams(8, 8, 0, 1, 5, 0, 1)
+    st = capi.Stats(); st.struct_size -= 512; st.rays = 77
+    out = np.zeros((8, 8, 4), np.uint8)
+    assert gpu.lib.mirt_render(gpu.h, C.byref(p), None, None, out.ctypes.data_as(C.c_void_p), C.byref(st)) == -1
+    assert b"mirt_stats.struct_size" in gpu.lib.mirt_last_error(gpu.h) and st.rays == 77 and not out.any()
+    p.struct_size += 4
+    assert gpu.lib.mirt_render(gpu.h, C.byref(p), None, None, out.ctypes.data_as(C.c_void_p), None) == -1 and not out.any()
+    bad = s.as_struct(); bad.struct_size = 0
+    assert gpu.lib.mirt_upload_scene(gpu.h, C.byref(bad)) == -1
 
 
 @pytest.mark.parametrize("world", ["cornell", "spheres4", "spheres", "two_boxes"])

@@ -83,6 +83,17 @@ def test_traceray_through_the_cpp_api_matches_the_c_abi(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_tracer_follows_a_rebuilt_world():
+    """The reference reads the live pointer graph on every TraceRay (HomemadeRayTracer.cpp:162).  Here the tracer keeps a
+    flattened copy on the device: after DeconstructWorld + ConstructWorld(other id) on the same World object it must
+    render the new world, not the cached one."""
+    first, second = hostapi.render_rebuilt(hostapi.WORLD_CORNELL, hostapi.WORLD_FOUR_SPHERES, 64, 48, 4)
+    assert np.array_equal(first, hostapi.render(hostapi.WORLD_CORNELL, 64, 48, 4))
+    assert np.array_equal(second, hostapi.render(hostapi.WORLD_FOUR_SPHERES, 64, 48, 4))
+    assert not np.array_equal(first, second)
+
+
+@pytest.mark.gpu
 def test_example_program_renders_a_ppm(tmp_path):
     hostapi.ensure_built()
     exe = os.path.join(os.path.dirname(capi.LIB_PATH), "cornell_example")

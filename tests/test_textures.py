@@ -54,6 +54,20 @@ def test_oracle_sample_known_answers(orc):
     assert np.array_equal(orc.tex_sample_batch(one, 0, edge_uv(64, 3)), np.tile((np.array([10, 20, 30], F) / F(255.0))[None], (64, 1)))
 
 
+def test_tga_decoder_id_field_and_colormap_origin(tmp_path):
+    """Pins a deliberate deviation from the reference's vendored reader (tga_reader.cpp): that one never skips the image-ID
+    field (its palette and pixels start at byte 18 whatever header byte 0 says, tga_reader.cpp:58,75-83) and evaluates
+    `byte & 0xFF - colormapOrigin` as `byte & (0xFF - origin)` (tga_reader.cpp:156).  DecodeTGA follows the TGA
+    specification instead -- ID field skipped, index minus first-entry index -- so files with neither (the reference's own
+    asset among them) decode to the same texels and legal files with either decode correctly rather than to noise."""
+    img = H.synthetic_texture(13, 9, 11, "checker")
+    for kind, rle, idb, org in (("rgb24", False, b"an image id", 0), ("gray", False, b"\x00\x01\x02", 0), ("cmap24", False, b"", 7),
+                                ("cmap32", True, b"xy", 100), ("cmap24", True, b"", 191)):
+        path = str(tmp_path / f"{kind}{int(rle)}{len(idb)}{org}.tga")
+        exp = H.write_tga(path, img, kind, rle, "ul", id_bytes=idb, cmap_origin=org)
+        assert np.array_equal(hostapi.decode_tga(path), exp), (kind, rle, idb, org)
+
+
 @pytest.mark.parametrize("kind,rle,origin", [(k, r, o) for k, r, o in itertools.product(("rgb24", "rgb32", "gray", "cmap24", "cmap32"), (False, True), ("ll", "ul", "lr", "ur"))])
 def test_tga_decoder(tmp_path, kind, rle, origin):
     img = H.synthetic_texture(19, 11, 5, "checker")
