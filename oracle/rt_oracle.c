@@ -371,11 +371,14 @@ static int bvh_hit(const orc_scene *sc, int32_t child, const ray_t *r, float t_m
     return hitMe;
 }
 
+static int bvh_hit_ordered(const orc_scene *sc, const ray_t *r, float t_min, float *t_max, hit_t *rec, orc_stats *st);
+
 static int world_hit(const orc_scene *sc, const ray_t *r, float t_min, float t_max, uint32_t flags,
                      hit_t *rec, orc_stats *st)
 {
     rec->mat = -1; rec->prim = -1;
     if (st) st->rays++;
+    if (flags & ORC_FLAG_ACCEL_ORDERED) return bvh_hit_ordered(sc, r, t_min, &t_max, rec, st);
     if (flags & ORC_FLAG_ACCEL_LIST) {
         int any = 0;
         for (uint32_t o = 0; o < sc->n_objects; ++o) any |= object_hit(sc, o, r, t_min, &t_max, rec, st);
@@ -603,6 +606,71 @@ static box_t object_box(const orc_scene *sc, uint32_t obj)
     b.mn = v_add(b.mn, off); b.mx = v_add(b.mx, off);                      /* Hitables.cpp:175-180 */
     return b;
 }
+/* NOT in the reference: the near-first walk the library runs under MIRT_FLAG_ACCEL_ORDERED / _AUTO (rt_kernels.h
+ * closest_bvh2), restated on the host for its work counters (bench.py prices the BVH workloads with nodes_visited =
+ * boxes tested and prims_tested of THIS walk, not of the reference's left-first one, which tests several times more) and as a
+ * second opinion on its hits.  Each child's box is tested in the parent with AABB::Hit's arithmetic (AABB.cpp:5-21, 1/dir
+ * hoisted) against the current t_max; the child entered nearer goes first.  A node's box culls on t_max <= t_min like
+ * AABB.cpp:17; an object's box -- the reference never box-tests an object -- only on t_max < t_min.  The root's own box is
+ * not tested.  Object boxes come from g_ordered_obox, set by the entry points below for the duration of a call. */
+static const box_t *g_ordered_obox;
+static int slab_ordered(box_t b, const ray_t *r, v3 invd, float t_min, float t_max, int is_object, float *t_near)
+{
+    for (unsigned a = 0; a < 3; ++a) {
+        float id = v_get(invd, a);
+        float t0 = (v_get(b.mn, a) - v_get(r->org, a)) * id;
+        float t1 = (v_get(b.mx, a) - v_get(r->org, a)) * id;
+        if (id < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+        t_min = W32_MAX(t0, t_min);
+        t_max = W32_MIN(t1, t_max);
+    }
+    *t_near = t_min;
+    return is_object ? !(t_max < t_min) : !(t_max <= t_min);
+}
+static box_t ordered_child_box(const orc_scene *sc, int32_t c)
+{
+    if (c < 0) return g_ordered_obox[~c];
+    box_t b = { ld3(sc->node_min + 3 * (size_t)c), ld3(sc->node_max + 3 * (size_t)c) };
+    return b;
+}
+static int bvh_hit_ordered(const orc_scene *sc, const ray_t *r, float t_min, float *t_max, hit_t *rec, orc_stats *st)
+{
+    int32_t stack[128]; int sp = 0, any = 0;
+    int32_t cur = sc->root;
+    const v3 invd = V(1.0f / r->dir.x, 1.0f / r->dir.y, 1.0f / r->dir.z);
+    for (;;) {
+        if (cur >= 0) {
+            const int32_t l = sc->node_left[cur], rr = sc->node_right[cur];
+            float tl = 0.0f, tr = 0.0f;
+            int hl = 0, hr = 0;
+            if (l != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hl = slab_ordered(ordered_child_box(sc, l), r, invd, t_min, *t_max, l < 0, &tl); }
+            if (rr != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hr = slab_ordered(ordered_child_box(sc, rr), r, invd, t_min, *t_max, rr < 0, &tr); }
+            if (hl && hr) {
+                const int left_first = tl <= tr;
+                if (sp < 128) stack[sp++] = left_first ? rr : l;
+                cur = left_first ? l : rr;
+                continue;
+            }
+            if (hl) { cur = l; continue; }
+            if (hr) { cur = rr; continue; }
+        } else if (cur != ORC_CHILD_NONE) {
+            any |= object_hit(sc, (uint32_t)~cur, r, t_min, t_max, rec, st);
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return any;
+}
+static box_t *ordered_begin(const orc_scene *sc, uint32_t flags)
+{
+    if (!(flags & ORC_FLAG_ACCEL_ORDERED)) return NULL;
+    box_t *b = (box_t *)malloc((sc->n_objects ? sc->n_objects : 1) * sizeof *b);
+    for (uint32_t o = 0; b && o < sc->n_objects; ++o) b[o] = object_box(sc, o);
+    g_ordered_obox = b;
+    return b;
+}
+static void ordered_end(box_t *b) { if (b) { g_ordered_obox = NULL; free(b); } }
+
 void orc_object_bounds(const orc_scene *sc, float *bmin, float *bmax)
 {
     for (uint32_t o = 0; o < sc->n_objects; ++o) {
@@ -717,12 +785,14 @@ void orc_world_hit_batch(const orc_scene *sc, const float *org, const float *dir
                          float t_min, float t_max, uint32_t flags, orc_hit *out, orc_stats *st)
 {
     orc_stats s; memset(&s, 0, sizeof s);
+    box_t *ob = ordered_begin(sc, flags);
     for (size_t i = 0; i < nray; ++i) {
         ray_t r = { ld3(org + 3 * i), ld3(dir + 3 * i) };
         hit_t h; memset(&h, 0, sizeof h);
         int hit = world_hit(sc, &r, t_min, t_max, flags, &h, &s);
         hit_store(out + i, &h, hit);
     }
+    ordered_end(ob);
     if (st) *st = s;
 }
 
@@ -816,6 +886,7 @@ void orc_trace(const orc_scene *sc, const orc_camera *cam, uint32_t width, uint3
                uint32_t flags, int rng_kind, int n_threads, float *sum_rgb, orc_stats *st)
 {
     orc_stats total; memset(&total, 0, sizeof total);
+    box_t *ordered_boxes = ordered_begin(sc, flags);
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
@@ -856,6 +927,7 @@ void orc_trace(const orc_scene *sc, const orc_camera *cam, uint32_t width, uint3
             total.prims_tested += ls.prims_tested; total.depth_cutoffs += ls.depth_cutoffs;
         }
     }
+    ordered_end(ordered_boxes);
     if (st) *st = total;
 }
 

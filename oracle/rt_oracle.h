@@ -93,6 +93,8 @@ enum {
     ORC_FLAG_ONE_SPP        = 1,   /* HomemadeRayTracer.cpp:114-121                         */
     ORC_FLAG_NORMAL_DISPLAY = 2,   /* HomemadeRayTracer.cpp:164-167                         */
     ORC_FLAG_ACCEL_LIST     = 4,   /* closest hit by a linear pass over all objects         */
+    ORC_FLAG_ACCEL_ORDERED  = 32,  /* not in the reference: the library's near-first walk of the tree (rt_kernels.h
+                                      closest_bvh2), restated for its work counters; same closest t            */
     ORC_FLAG_RECURSIVE      = 8    /* oracle only: evaluate emitted + atten*Sample() in the
                                       reference's recursive order instead of forward
                                       throughput order                                      */

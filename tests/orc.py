@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
 LIB = os.path.join(ODIR, "libmirt_oracle.so")
 
-FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_RECURSIVE = 1, 2, 4, 8
+FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_RECURSIVE, FLAG_ACCEL_ORDERED = 1, 2, 4, 8, 32
 RNG_PHILOX, RNG_STREAM, RNG_ENTROPY = 0, 1, 2
 HIT_DTYPE = capi.HIT_DTYPE
 

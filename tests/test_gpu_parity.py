@@ -310,6 +310,14 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
         osum, st = orc.trace(s, cam, w, h, 6, 50, 0x5EED, capi.FLAG_ACCEL_LIST)
         H.assert_bits(a["sum"], osum, "ordered image")
         assert a["stats"].rays == st.rays
+    # the oracle's restatement of the near-first walk on the library's own tree: whole records, tie winners included
+    capi.build_bvh(s)
+    o2, st2 = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, orc.FLAG_ACCEL_ORDERED)
+    H.assert_hits_equal(g, o2, "ordered walk vs its restatement", uv_tol=2e-6)
+    a = gpu.render(w, h, 3, 50, 7, capi.FLAG_ACCEL_ORDERED)
+    osum, st3 = orc.trace(s, cam, w, h, 3, 50, 7, orc.FLAG_ACCEL_ORDERED)
+    H.assert_bits(a["sum"], osum, "ordered image vs ordered oracle")
+    assert a["stats"].rays == st3.rays and 0 < st3.nodes_visited
     # the same tree, host-built through the C ABI, walked in the reference's order by oracle and device alike
     depth = capi.build_bvh(s)
     assert 1 <= depth <= 40 and len(s.nodes[2]) == max(1, s.n_objects - 1)
