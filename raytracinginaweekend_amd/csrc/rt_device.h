@@ -15,6 +15,15 @@
 
 namespace mirt {
 
+// MIRT_TEXP: ablation bits for timing experiments on k_trace (tools/ablate_trace.sh, results in
+// profiles/r02_trace_ablation.txt); never set in the product, results are wrong by design.  1: metal/dielectric shaded as
+// Lambertian (upper bound of what regrouping by material can save), 2: hardware sqrt approximation instead of the
+// correctly rounded expansion, 4: no rejection rounds after the first candidate, 8: no radiance store
+#ifndef MIRT_TEXP
+#define MIRT_TEXP 0
+#endif
+#define MIRT_SQRT(x) ((MIRT_TEXP & 2) ? __builtin_amdgcn_sqrtf(x) : __builtin_sqrtf(x))
+
 // ----------------------------------------------------------------------------- Vec3.h / Ray.h
 struct f3 { float x, y, z; };
 struct Ray { f3 o, d; };
@@ -57,7 +66,7 @@ __device__ __forceinline__ float div_by(const DivBy &q, float x)
 __device__ __forceinline__ f3 normalize(f3 a)                                                         // Vec3.h:100-103
 {
     float l2 = dot(a, a);
-    float l = __builtin_sqrtf(l2);
+    float l = MIRT_SQRT(l2);
     // three quotients, one denominator: div_by when every active lane is inside its range -- all components in
     // [2^-40, 2^19] in magnitude, the largest at least 2^-19, which puts l in [2^-20, 2^20]; exact zeros, NaN and
     // out-of-range vectors take the plain divides, whole wave
@@ -334,7 +343,7 @@ __device__ __forceinline__ bool refract(f3 v, f3 n, float ni_over_nt, f3 &refrac
     float dt = dot(v, n);
     float disc = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
     bool ret = disc > 0;
-    if (ret) refracted = scale(v - scale(n, dt), ni_over_nt) - scale(n, __builtin_sqrtf(disc));
+    if (ret) refracted = scale(v - scale(n, dt), ni_over_nt) - scale(n, MIRT_SQRT(disc));
     return ret;
 }
 // Optics.h:27-32; pow(float,int) -> x^5 in double rounded once, as the oracle defines it.
@@ -358,6 +367,7 @@ enum { NEED_NONE = 0, NEED_SPHERE = 1, NEED_UNORM = 2 };
 // independently of the draw) skips its draws; the explicit-stream hooks never skip.
 __device__ __forceinline__ uint32_t scatter_need(uint32_t kind, f3 dir_in, f3 nrm, bool lazy)
 {
+    if ((MIRT_TEXP & 1) && kind != MIRT_MAT_DIFFUSE_LIGHT) kind = MIRT_MAT_LAMBERTIAN;
     const bool front = dot(dir_in, nrm) < 0;                                 // selects: the kinds of a wave are mixed anyway
     const bool sphere = (kind == MIRT_MAT_METAL) | ((kind == MIRT_MAT_LAMBERTIAN) & (front | !lazy));
     return sphere ? NEED_SPHERE : (kind == MIRT_MAT_DIELECTRIC ? NEED_UNORM : NEED_NONE);
@@ -401,6 +411,7 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
     }
     o.emits = false;
     uint32_t kind = m.kind;
+    if ((MIRT_TEXP & 1) && kind != MIRT_MAT_DIFFUSE_LIGHT) kind = MIRT_MAT_LAMBERTIAN;
     if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
         o.alive = dot(dir_in, nrm) < 0;
         o.atten = albedo;

@@ -219,7 +219,7 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     const float inv2a = __builtin_amdgcn_rcpf(two_a), t_lo = t_min * 0.99999f, t_hi = t_min * 1.00001f;
     auto resolve = [&]() {
         if (p_idx >= 0) {
-            const float sq = __builtin_sqrtf(p_disc);
+            const float sq = MIRT_SQRT(p_disc);
             const float n1 = -p_b - sq, n2 = -p_b + sq;
             const float q1 = n1 * inv2a;
             const bool first = q1 > t_hi, second = q1 < t_lo;
@@ -527,7 +527,7 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
         unorm = map_unorm(r[0]);
         w0 = r[0]; w1 = r[1]; w2 = r[2];                       // read only when need == NEED_SPHERE
-        pending = (need == NEED_SPHERE) & !candidate_inside(r);
+        pending = (need == NEED_SPHERE) & !candidate_inside(r) & !(MIRT_TEXP & 4);
     }
     unsigned long long mask;
     while ((mask = __ballot(pending)) != 0ull) {
@@ -918,7 +918,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
         if (ready && done) {
-            a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            if (!(MIRT_TEXP & 8)) a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
             atomicAdd(&s_hist[depth < 63u ? depth : 63u], 1u);
             if (depth > 63u) atomicAdd(&s_hist[64], depth - 63u);
             live = false;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Writes profiles/<name>.txt from the outputs of tools/final_profile.sh <tag> (merged back under gpurun_out/).
-Usage: python tools/profile_summary.py <tag> <name>"""
+"""Writes profiles/<name>.txt from the outputs of tools/final_profile.sh <tag> <workload> <spp> <size> (merged back under
+gpurun_out/) and records the HBM traffic of the PMC launch in profiles/pmc_traffic.json under the workload's name.
+Usage: python tools/profile_summary.py <tag> <name> [workload spp WxH]"""
 import io
 import json
 import os
@@ -20,20 +21,26 @@ def counters(db, kernel_like):
     return dict(c.execute(f"select counter_name, sum(value) from counters_collection where {namecol} like ? group by 1", (kernel_like,)).fetchall())
 
 
-def main(tag, name):
+def kname_hint(out, tag):
+    return json.loads(open(os.path.join(out, f"bench_{tag}.json")).read().strip().split("\n")[-1])["roofline"]["kernel"]
+
+
+def main(tag, name, workload="cornell", spp=256, size="1024x1024"):
+    w, h = (int(x) for x in size.split("x"))
     out = os.path.join(ROOT, "gpurun_out")
     prof = os.path.join(out, "prof")
     buf = io.StringIO()
     with redirect_stdout(buf):
         print(f"# {name}: rocprofv3 summaries, one MI355X (tools/final_profile.sh {tag})")
-        print("# (a) rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (Cornell 1024^2 @1024 spp: 1 warmup + 3 timed + 1 instrumented render)")
+        print(f"# (a) rocprofv3 --kernel-trace --stats -- python3 bench.py --workload {workload} --no-cpu-baseline   (1 warmup + 3 timed + 3 instrumented renders)")
         R.kernel_stats(os.path.join(prof, f"{tag}_kt", "b_results.db"))
         print("\n# bench line of the profiled run:")
         print(open(os.path.join(out, f"bench_{tag}_prof.json")).read().strip().split("\n")[-1])
         print("\n# bench line of the unprofiled run (with the CPU baseline):")
         print(open(os.path.join(out, f"bench_{tag}.json")).read().strip().split("\n")[-1])
         pm = os.path.join(prof, f"{tag}_pmc")
-        print(f"\n# (b) tools/pmc.sh 256 {tag}_pmc: one render at 256 spp (one k_trace launch of 268,435,456 paths), separate --pmc passes")
+        paths = float(w) * h * spp
+        print(f"\n# (b) WORLD={workload} MIRT_SIZE={size} tools/pmc.sh {spp} {tag}_pmc: one render at {spp} spp (one k_trace launch of {int(paths):,} paths), separate --pmc passes")
         R.kernel_stats(os.path.join(pm, "kt", "c_results.db"))
         c = {}
         for p in ("sq1", "sq2", "sq3", "grbm", "fetch", "write"):
@@ -41,10 +48,9 @@ def main(tag, name):
         for k in sorted(c):
             print(f"k_trace  {k:26s} {c[k]:22.0f}")
         kt = sqlite3.connect(os.path.join(pm, "kt", "c_results.db")).execute("select sum(end-start) from kernels where name like '%k_trace%'").fetchone()[0] / 1e6
-        paths = 268435456.0
         rays = paths * json.loads(open(os.path.join(out, f"bench_{tag}.json")).read().strip().split("\n")[-1])["rays_per_sample"]
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 1024
-        print("\n# Derived (k_trace):")
+        print(f"\n# Derived ({kname_hint(out, tag)}):")
         print(f"#   launch {kt:.2f} ms for {paths / 1e6:.1f} M paths, {rays / 1e6:.1f} M rays -> {rays / kt / 1e6:.2f} Grays/s")
         print(f"#   VALU instructions per 64 rays {c['SQ_INSTS_VALU'] * 64 / rays:.0f}  (SALU {c['SQ_INSTS_SALU'] * 64 / rays:.0f}, LDS {c['SQ_INSTS_LDS'] * 64 / rays:.0f})")
         print(f"#   VALU lane utilisation  THREAD_CYCLES_VALU / (ACTIVE_INST_VALU x 64) = {100 * c['SQ_THREAD_CYCLES_VALU'] / (c['SQ_ACTIVE_INST_VALU'] * 64):.1f} %")
@@ -54,13 +60,24 @@ def main(tag, name):
         print(f"#   wave-cycles: issuing {100 * c['SQ_ACTIVE_INST_ANY'] / wc:.1f} %, issue-stalled (pipe taken by another wave) {100 * c['SQ_WAIT_INST_ANY'] / wc:.1f} %, waiting (s_waitcnt) {100 * c['SQ_WAIT_ANY'] / wc:.1f} %")
         hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
         print(f"#   HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KB (x2 on gfx950), WRITE_SIZE {c['WRITE_SIZE']:.0f} KB -> {hbm / 1e9:.2f} GB per launch for {paths * 16 / 1e9:.2f} GB of radiance slots = {hbm / kt / 1e6:.0f} GB/s")
-        json.dump({"kernel": "k_trace<true,false>", "workload": f"Cornell box 3-ball 1024x1024, 256 spp in one launch (tools/pmc.sh 256 {tag}_pmc)",
-                   "paths_per_launch": int(paths), "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
-                   "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)"},
-                  open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+        kname = json.loads(open(os.path.join(out, f"bench_{tag}.json")).read().strip().split("\n")[-1])["roofline"]["kernel"]
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        try:
+            allw = json.load(open(path))
+            if "kernel" in allw:                                   # the round-1 flat form held Cornell only
+                allw = {"cornell": allw}
+        except (OSError, ValueError):
+            allw = {}
+        allw[workload] = {"kernel": kname, "workload": f"{workload} {size}, {spp} spp in one launch (tools/pmc.sh {spp} {tag}_pmc)",
+                          "paths_per_launch": int(paths), "fetch_size_kb": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"], "hbm_bytes_per_launch": hbm,
+                          "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)"}
+        json.dump(allw, open(path, "w"), indent=1)
     open(os.path.join(ROOT, "profiles", f"{name}.txt"), "w").write(buf.getvalue())
     print(buf.getvalue()[-1500:])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    if len(sys.argv) >= 6:
+        main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5])
+    else:
+        main(sys.argv[1], sys.argv[2])
