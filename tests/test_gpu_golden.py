@@ -117,6 +117,28 @@ def test_full_size_properties(gpu):
     assert np.allclose(c["pixels"][0, 0], np.sqrt(np.float32([0.85, 0.9, 1.0])), atol=1e-6)
 
 
+def test_c4_full_frame_properties(gpu):
+    """BASELINE config 3 at its full frame (1920x1080, ~1 M spheres, the library's own tree walked near-first in resumable
+    slices): run-to-run identical, sample ranges compose exactly, ray statistics plausible, nothing brighter than the sky."""
+    s, cam = scene.spheres_world(1920 / 1080, grid=500, look_from=(26.0, 6.0, 6.0))
+    assert s.n_objects > 900000
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w, h = 1920, 1080
+    a = gpu.render(w, h, 4, 50, 9, capi.FLAG_ACCEL_AUTO, want=("sum", "pixels"))
+    b = gpu.render(w, h, 4, 50, 9, capi.FLAG_ACCEL_AUTO, want=("sum",))
+    assert a["sum"].tobytes() == b["sum"].tobytes()
+    assert a["stats"].samples == w * h * 4 and 2.3 < a["stats"].rays / a["stats"].samples < 3.0
+    lo = gpu.render(w, h, 1, 50, 9, capi.FLAG_ACCEL_AUTO, want=("sum",))["sum"]
+    hi = gpu.render(w, h, 3, 50, 9, capi.FLAG_ACCEL_AUTO, spp_begin=1, want=("sum",))
+    d_lo = lo.copy()
+    # [0,1) then [1,4) accumulated on the device == [0,4)
+    c1 = gpu.render_progressive(w, h, 0, 1, 50, 9, capi.FLAG_ACCEL_AUTO, want=())
+    c2 = gpu.render_progressive(w, h, 1, 3, 50, 9, capi.FLAG_ACCEL_AUTO, want=("sum",))
+    assert c2["sum"].tobytes() == a["sum"].tobytes() and c1["stats"].samples + c2["stats"].samples == a["stats"].samples
+    assert hi["stats"].rays + gpu.render(w, h, 1, 50, 9, capi.FLAG_ACCEL_AUTO, want=())["stats"].rays == a["stats"].rays and d_lo.any()
+    assert np.isfinite(a["pixels"]).all() and a["pixels"].min() >= 0.0 and a["pixels"].max() <= np.sqrt(np.float32(1.0)) + 1e-6   # no emitters: nothing brighter than the sky
+
+
 def test_c5_frame_size(gpu):
     """BASELINE config 5 is 4096^2: the frame renders (2 spp here), sample ranges and pixel/sample tilings compose exactly,
     and a 1024^2 crop of samples is the same image whichever way the batches were cut (16.8 M pixels x 2 spp = 33.5 M paths)."""

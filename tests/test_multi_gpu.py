@@ -110,3 +110,27 @@ def test_cpp_tracer_over_several_devices():
     img, info, rays = hostapi.render_devices(hostapi.WORLD_CORNELL, 64, 64, 8, [0, 0])
     assert info.n_devices == 2 and [info.spp_count[i] for i in range(2)] == [4, 4] and rays > 64 * 64 * 8
     assert (np.abs(img.astype(int) - one.astype(int)) <= 1).all() and (img != one).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_c5_eight_shards_of_a_4096_frame(gpu):
+    """BASELINE config 5 in shape: a 4096^2 frame whose samples are split over EIGHT ranks and summed onto rank 0 (201 MB per
+    rank).  One GPU plays all eight (peer reduce, device 0 listed eight times); the sum must be the eight single-range renders
+    added in rank order, bit for bit, and equal the one-device image up to re-association."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w = h = 4096; spp = 16
+    with capi.MultiContext([0] * 8) as m:
+        m.upload_scene(s); m.set_camera(cam)
+        r = m.render(w, h, spp, 50, 0xC5, capi.FLAG_ACCEL_AUTO, want=("sum", "rgba8"))
+    info = r["info"]
+    assert info.n_devices == 8 and info.reduce_bytes == w * h * 12 and [info.spp_count[i] for i in range(8)] == [2] * 8
+    expect = None
+    for i in range(8):
+        part = gpu.render(w, h, 2, 50, 0xC5, capi.FLAG_ACCEL_AUTO, spp_begin=2 * i, want=("sum",))["sum"]
+        expect = part if expect is None else expect + part
+    assert np.array_equal(np.where(r["sum"] == 0, 0, r["sum"]).view(np.uint32), np.where(expect == 0, 0, expect).view(np.uint32))
+    one = gpu.render(w, h, spp, 50, 0xC5, capi.FLAG_ACCEL_AUTO, want=("sum", "rgba8"))
+    assert r["stats"].rays == one["stats"].rays
+    assert np.allclose(r["sum"], one["sum"], rtol=4e-6, atol=2e-6)
+    assert (np.abs(r["rgba8"].astype(np.int16) - one["rgba8"].astype(np.int16)) <= 1).all()
