@@ -65,6 +65,7 @@ struct mirt_ctx {
     bool small_scene = false;       // the primitive table is small enough for the list walk (ACCEL_AUTO)
     mirt_camera cam{};
     DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
+    DevBuf d_mdq, d_rdy;            // MIRT_DEFER_MD builds: per-wave queues of the second (metal/dielectric) stream
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -166,7 +167,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -496,6 +497,15 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
     }
     HIPCHK(c, hipMemsetAsync(counts, 0, n_batches * per_batch * sizeof(uint32_t), st));
+#if MIRT_DEFER_MD
+    if (mode == 0 && c->sc.n_textures == 0) {                        // the second stream's per-wave queues (experimental build)
+        if (fixed) return fail(c, MIRT_ERR_STATE, "mirt_render_device_noalloc: not available in a MIRT_DEFER_MD build");
+        const size_t waves = (size_t)max_grid * (MIRT_BLOCK / 64);
+        if (c->d_mdq.ensure(waves * MDQ_PLANES * MDQ_CAP * sizeof(float4)) || c->d_rdy.ensure(waves * RDY_PLANES * RDY_CAP * sizeof(float4)))
+            return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the second stream's queues failed");
+        a.mdq = (float4 *)c->d_mdq.p; a.rdy = (float4 *)c->d_rdy.p;
+    }
+#endif
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);

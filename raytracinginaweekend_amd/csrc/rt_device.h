@@ -401,7 +401,9 @@ __device__ __forceinline__ f3 albedo_of(const M &m, const TexRec *texs, const ui
 // DEFAULTS: also give the fields a material does not touch their values of the reference (zero: the caller's
 // `emmitted.zero()`, HomemadeRayTracer.cpp:173, and the default-constructed outputs).  The render kernel passes false
 // and reads atten/dir only when alive, emitted only when emits -- which saves it the register moves.
-template <bool DEFAULTS = true, class M>
+// PART: 0 the whole of Scatter; 1 without the metal/dielectric branch, 2 only that branch (the render kernel's second,
+// material-sorted stream shades those two kinds apart from the rest; the caller routes each vertex to the right part)
+template <bool DEFAULTS = true, int PART = 0, class M>
 __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
 {
     if (DEFAULTS) {
@@ -412,12 +414,12 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
     o.emits = false;
     uint32_t kind = m.kind;
     if ((MIRT_TEXP & 1) && kind != MIRT_MAT_DIFFUSE_LIGHT) kind = MIRT_MAT_LAMBERTIAN;
-    if (kind == MIRT_MAT_LAMBERTIAN) {                                  // Materials.cpp:19-33
+    if (PART != 2 && kind == MIRT_MAT_LAMBERTIAN) {                     // Materials.cpp:19-33
         o.alive = dot(dir_in, nrm) < 0;
         o.atten = albedo;
         f3 target = (pos + nrm) + sphere_pt;
         o.dir = target - pos;
-    } else if (kind == MIRT_MAT_METAL || kind == MIRT_MAT_DIELECTRIC) {
+    } else if (PART != 1 && (PART == 2 || kind == MIRT_MAT_METAL || kind == MIRT_MAT_DIELECTRIC)) {
         f3 uv = normalize(dir_in);                                      // shared by both (Materials.cpp:102,175)
         f3 refl = reflect(uv, nrm);                                     // Materials.cpp:102,209
         if (kind == MIRT_MAT_METAL) {                                   // Materials.cpp:99-106

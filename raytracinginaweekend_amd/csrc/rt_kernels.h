@@ -724,7 +724,17 @@ struct TraceArgs {
     uint32_t max_depth, flags, k0, k1;
     uint32_t tiles_x;              // > 0: path ids run over 8x8 pixel tiles (tile_pixel), tiles_x = width / 8
     uint32_t slice_want;           // ACCEL 3: finished walks that end a slice (bvh2_slice)
+    // second stream (MIRT_DEFER_MD, list walk): per-wave queues in HBM, plane-major.  mdq: MDQ_PLANES float4 planes of MDQ_CAP
+    // parked metal/dielectric vertices; rdy: RDY_PLANES planes of RDY_CAP rays ready to be traced.  NULL: not used.
+    float4 *mdq, *rdy;
 };
+#ifndef MIRT_DEFER_MD
+#define MIRT_DEFER_MD 0
+#endif
+#define MDQ_CAP 128u
+#define MDQ_PLANES 5u
+#define RDY_CAP 256u
+#define RDY_PLANES 3u
 // 128 entries: topped up whenever fewer than 64 remain, so one pass always serves every idle lane (list walk:
 // the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
 // outnumber what is left (BVH walks: iterations are long, LDS is what limits residency).
@@ -776,7 +786,71 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     WalkState ws; ws.cur = 0; ws.best = -1; ws.t_max = 0.0f; ws.sp = 0; ws.invd = mk(0, 0, 0);   // ACCEL 3 only
     bool walking = false;
 
+    // ---- second stream: metal / dielectric vertices are parked (after their draws) and shaded 64 at a time
+    constexpr bool DEFER = MIRT_DEFER_MD && ACCEL == 0 && !TEX;
+    uint32_t q_cnt = 0, r_cnt = 0;                                   // wave-uniform: parked vertices, ready rays
+    const uint32_t gwave = blockIdx.x * (MIRT_BLOCK / 64) + wave;
+    float4 *const mdq = DEFER ? a.mdq + (size_t)gwave * MDQ_PLANES * MDQ_CAP : nullptr;
+    float4 *const rdy = DEFER ? a.rdy + (size_t)gwave * RDY_PLANES * RDY_CAP : nullptr;
+    auto service = [&](uint32_t n) {                                  // the top n parked vertices, one per lane
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the parking stores of earlier passes have landed ...
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         // ... before other lanes read them
+        bool cont = false, dead = false;
+        f3 so = mk(0, 0, 0), sd = mk(0, 0, 0), sthr = mk(0, 0, 0);
+        uint32_t spid = 0, sdepth = 0, ssl = 0;
+        if (lane < n) {
+            const uint32_t e = q_cnt - n + lane;
+            const float4 p0 = mdq[e], p1 = mdq[MDQ_CAP + e], p2 = mdq[2u * MDQ_CAP + e], p3 = mdq[3u * MDQ_CAP + e], p4 = mdq[4u * MDQ_CAP + e];
+            const f3 pos = mk(p0.x, p0.y, p0.z), din = mk(p0.w, p1.x, p1.y), nrm = mk(p1.z, p1.w, p2.x), spt = mk(p2.y, p2.z, p2.w);
+            sthr = mk(p3.x, p3.y, p3.z); spid = __float_as_uint(p3.w);
+            sdepth = __float_as_uint(p4.x); ssl = __float_as_uint(p4.z);
+            const uint32_t smi = __float_as_uint(p4.y);
+            const MatRec *SM = (PLDS || smi < a.sc.lds_mats) ? (const MatRec *)((const unsigned char *)lv.mats + __umul24(smi, (uint32_t)sizeof(MatRec))) : (a.sc.mats + smi);
+            Scat s;
+            scatter_finish<false, 2>(*SM, mk(SM->albedo[0], SM->albedo[1], SM->albedo[2]), din, pos, nrm, spt, spt.x, s);
+            if (s.alive) { cont = true; so = pos; sd = s.dir; sthr = sthr * s.atten; }
+            else dead = true;
+        }
+        if (dead) {                                                   // absorbed by the metal: thr * (0,0,0), :173
+            const f3 z = scale(sthr, 0.0f);
+            a.rad[spid] = make_float4(z.x, z.y, z.z, 0.0f);
+            atomicAdd(&s_hist[sdepth < 63u ? sdepth : 63u], 1u);
+            if (sdepth > 63u) atomicAdd(&s_hist[64], sdepth - 63u);
+        }
+        const unsigned long long cm = __ballot(cont);
+        if (cont) {
+            const uint32_t e = r_cnt + rank_in(cm);
+            rdy[e] = make_float4(so.x, so.y, so.z, sd.x);
+            rdy[RDY_CAP + e] = make_float4(sd.y, sd.z, sthr.x, sthr.y);
+            rdy[2u * RDY_CAP + e] = make_float4(sthr.z, __uint_as_float(spid), __uint_as_float(sdepth + 1u), __uint_as_float(ssl));
+        }
+        r_cnt += (uint32_t)__popcll(cm);
+        q_cnt -= n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    };
+
     for (;;) {
+        if constexpr (DEFER) {
+            if (q_cnt >= 64u && r_cnt + 64u <= RDY_CAP) service(64u);
+            // idle lanes take ready rays before fresh camera rays
+            const unsigned long long idle0 = __ballot(!live);
+            if (idle0 != 0ull && r_cnt != 0u) {
+                const uint32_t n_idle = (uint32_t)__popcll(idle0);
+                const uint32_t take = n_idle < r_cnt ? n_idle : r_cnt;
+                const uint32_t rank = rank_in(idle0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (!live && rank < take) {
+                    const uint32_t e = r_cnt - 1u - rank;
+                    const float4 q0 = rdy[e], q1 = rdy[RDY_CAP + e], q2 = rdy[2u * RDY_CAP + e];
+                    o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y); thr = mk(q1.z, q1.w, q2.x);
+                    pid = __float_as_uint(q2.y); depth = __float_as_uint(q2.z);
+                    const uint32_t sl = __float_as_uint(q2.w);
+                    sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
+                    live = true;
+                }
+                r_cnt -= take;
+            }
+        }
         if constexpr (BIG_STASH) {
             // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
             if (cnt + 64u <= STASH_N && !exhausted) {
@@ -860,7 +934,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 }
             }
         }
-        if (__ballot(live) == 0ull) break;                          // pool exhausted, stash empty, every path ended
+        const unsigned long long live_now = __ballot(live);
+        if (live_now == 0ull) {                                     // pool exhausted, stash empty, every path ended
+            if constexpr (DEFER) { if (q_cnt != 0u) { service(q_cnt < 64u ? q_cnt : 64u); continue; } if (r_cnt != 0u) continue; }
+            break;
+        }
+        if constexpr (DEFER) {
+            // end of the launch (the refill above could not fill the wave): parked vertices need not wait for company any more
+            if (q_cnt != 0u && (uint32_t)__popcll(live_now) <= 16u && r_cnt + 64u <= RDY_CAP) service(q_cnt < 64u ? q_cnt : 64u);
+        }
 
         // ---- phase 1 (per lane): extend, HomemadeRayTracer.cpp:160-162, and classify the vertex
         bool done = false;
@@ -910,20 +992,44 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
         coop_draws<true>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
         // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
-        if (ready && !done) {
+        bool parked = false, retry = false;
+        if constexpr (DEFER) {
+            // metal / dielectric vertices leave the lane: their state goes to the wave's queue and the lane is free for another path
+            const bool md = ready && !done && ((M->kind & 2u) != 0u);             // MIRT_MAT_METAL = 2, MIRT_MAT_DIELECTRIC = 3
+            const unsigned long long mm = __ballot(md);
+            if (mm != 0ull) {
+                const uint32_t e = q_cnt + rank_in(mm);
+                if (md) {
+                    if (e < MDQ_CAP) {
+                        const uint32_t mi = (uint32_t)h.mat;
+                        const float sx = need == NEED_UNORM ? un : sp.x;
+                        mdq[e] = make_float4(h.pos.x, h.pos.y, h.pos.z, d.x);
+                        mdq[MDQ_CAP + e] = make_float4(d.y, d.z, h.nrm.x, h.nrm.y);
+                        mdq[2u * MDQ_CAP + e] = make_float4(h.nrm.z, sx, sp.y, sp.z);
+                        mdq[3u * MDQ_CAP + e] = make_float4(thr.x, thr.y, thr.z, __uint_as_float(pid));
+                        mdq[4u * MDQ_CAP + e] = make_float4(__uint_as_float(depth), __uint_as_float(mi), __uint_as_float(sample - a.spp0), 0.0f);
+                        parked = true;
+                    } else retry = true;                                         // queue full: the lane keeps its ray and meets this vertex again
+                }
+                const uint32_t n_md = (uint32_t)__popcll(mm);
+                q_cnt = (q_cnt + n_md < MDQ_CAP) ? q_cnt + n_md : MDQ_CAP;                // the stores are awaited where they are read (service)
+            }
+        }
+        if (ready && !done && !parked && !retry) {
             Scat s;
             const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
-            scatter_finish<ACCEL != 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
+            scatter_finish<ACCEL != 0, DEFER ? 1 : 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
+        if (parked) live = false;
         if (ready && done) {
             if (!(MIRT_TEXP & 8)) a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
             atomicAdd(&s_hist[depth < 63u ? depth : 63u], 1u);
             if (depth > 63u) atomicAdd(&s_hist[64], depth - 63u);
             live = false;
         }
-        if (ready) ++depth;
+        if (ready && !retry) ++depth;
     }
     __syncthreads();
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);

@@ -384,6 +384,27 @@ def test_million_spheres(gpu, orc):
         assert g["stats"].rays == ost.rays
 
 
+def test_material_stream_build_is_bit_identical(tmp_path):
+    """lib/libmirt_defer.so (build flag MIRT_DEFER_MD: metal and glass vertices parked in a per-wave queue and shaded 64 at a
+    time, profiles/r02_material_stream.txt) regroups work, never arithmetic: sums, ray counts and depth histograms equal the
+    product's bit for bit.  Each build renders in its own process (MIRT_LIB selects the library)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(os.path.dirname(capi.LIB_PATH), "libmirt_defer.so")
+    assert os.path.exists(variant), "build() compiles the variant next to libmirt.so"
+    for world, w, h, spp in (("cornell", 192, 192, 24), ("spheres4", 200, 100, 40), ("two_boxes", 128, 128, 8)):
+        got = []
+        for lib in (capi.LIB_PATH, variant):
+            out = str(tmp_path / f"{world}_{os.path.basename(lib)}.npz")
+            subprocess.run([sys.executable, os.path.join(root, "tools", "ab_image.py"), out, world, str(w), str(h), str(spp)],
+                           env=dict(os.environ, MIRT_LIB=lib), check=True, timeout=120, stdout=subprocess.DEVNULL)
+            got.append(np.load(out))
+        a, b = got
+        H.assert_bits(a["sum"], b["sum"], f"{world}: second-stream build")
+        assert int(a["rays"]) == int(b["rays"]) and np.array_equal(a["hist"], b["hist"])
+
+
 @pytest.mark.parametrize("world", list(WORLDS))
 def test_engines_identical(gpu, orc, world):
     """The persistent engine (k_trace, default) and the wavefront engine (k_bounce per depth) run the same per-path
