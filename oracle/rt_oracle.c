@@ -196,12 +196,52 @@ static int aabb_hit(v3 bmin, v3 bmax, const ray_t *r, float t_min, float t_max)
 /* ===================================================================================== */
 typedef struct { float t; v3 pos, nrm; float u, v; int mat; int prim; } hit_t;
 
+/* atan2f / asinf of CalculateUV, pinned by definition.  The reference calls the MSVC CRT's (Hitables.cpp:70-71), whose bits are
+ * not known here, and glibc's differ from the device library's in the last place.  Like Schlick's pow, the oracle and the
+ * device therefore evaluate ONE stated sequence of IEEE float operations (rt_device.h det_atan2f / det_asinf: classic argument
+ * reductions + single-precision minimax polynomials, error below 3 ulp): they agree bit for bit, and both stay closer to any
+ * correct libm than two libms are to each other. */
+static float det_atanf_pos(float x)
+{
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    const float z = x * x;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return y + p;
+}
+static float det_atan2f(float y, float x)
+{
+    const float PI = 3.14159265358979323846f, PIO2 = 1.5707963267948966f;
+    if (x != x || y != y) return NAN;
+    if (x == 0.0f) return y > 0.0f ? PIO2 : (y < 0.0f ? -PIO2 : 0.0f);
+    if (y == 0.0f) return x < 0.0f ? PI : 0.0f;
+    const float q = y / x;
+    const float a = det_atanf_pos(fabsf(q));
+    const float z = q < 0.0f ? -a : a;
+    const float w = x < 0.0f ? (y < 0.0f ? -PI : PI) : 0.0f;
+    return w + z;
+}
+static float det_asinf(float x)
+{
+    const float PIO2 = 1.5707963267948966f;
+    const float a = fabsf(x);
+    if (!(a <= 1.0f)) return NAN;
+    if (a < 1.0e-4f) return x;
+    float z, s;
+    const int big = a > 0.5f;
+    if (big) { z = 0.5f * (1.0f - a); s = sqrtf(z); } else { s = a; z = s * s; }
+    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * s + s;
+    if (big) { r = r + r; r = PIO2 - r; }
+    return x < 0.0f ? -r : r;
+}
+
 /* Hitables.cpp:62-78 (always executed by SphereHitable::Hit) */
 static void sphere_uv(hit_t *rec, v3 center)
 {
     v3 p = v_normalize(v_sub(rec->pos, center));
-    float theta = atan2f(p.z, p.x);
-    float phi = asinf(p.y);
+    float theta = det_atan2f(p.z, p.x);
+    float phi = det_asinf(p.y);
     rec->u = 1.0f - (theta + (float)M_PI) / (2.0f * (float)M_PI);
     rec->v = (phi + (float)M_PI / 2.0f) / (float)M_PI;
 }

@@ -296,6 +296,47 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
     return (t <= t_max) & (t >= t_min) & (a >= pr.ga[0]) & (a <= pr.ga[1]) & (b >= pr.ga[2]) & (b <= pr.gb[0]);
 }
 
+// ----------------------------------------------------------------------------- atan2f / asinf of CalculateUV, pinned by definition
+// The reference calls the MSVC CRT's atan2f and asinf (Hitables.cpp:70-71), whose bits are not known here; glibc's (the
+// oracle's host) and the device library's differ from each other in the last place, which used to show up as a texel's
+// width of difference on textured spheres.  Like Schlick's pow, both sides therefore evaluate ONE stated sequence of IEEE
+// float operations (single-precision minimax polynomials after the classic argument reductions, error below 3 ulp --
+// closer to any correctly working libm than two libms are to each other): the oracle and the device agree bit for bit.
+__device__ __forceinline__ float det_atanf_pos(float x)                       // x >= 0 (or NaN)
+{
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }            // tan(3 pi / 8): pi/2 - atan(1/x)
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }   // tan(pi / 8): pi/4 + atan((x-1)/(x+1))
+    const float z = x * x;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x;
+    return y + p;
+}
+__device__ __forceinline__ float det_atan2f(float y, float x)
+{
+    const float PI = 3.14159265358979323846f, PIO2 = 1.5707963267948966f;
+    if (x != x || y != y) return __builtin_nanf("");
+    if (x == 0.0f) return y > 0.0f ? PIO2 : (y < 0.0f ? -PIO2 : 0.0f);
+    if (y == 0.0f) return x < 0.0f ? PI : 0.0f;
+    const float q = y / x;
+    const float a = det_atanf_pos(__builtin_fabsf(q));
+    const float z = q < 0.0f ? -a : a;                                            // atan is odd
+    const float w = x < 0.0f ? (y < 0.0f ? -PI : PI) : 0.0f;
+    return w + z;
+}
+__device__ __forceinline__ float det_asinf(float x)
+{
+    const float PIO2 = 1.5707963267948966f;
+    const float a = __builtin_fabsf(x);
+    if (!(a <= 1.0f)) return __builtin_nanf("");                                  // outside the domain (and NaN), as asinf answers
+    if (a < 1.0e-4f) return x;
+    float z, s;
+    const bool big = a > 0.5f;
+    if (big) { z = 0.5f * (1.0f - a); s = __builtin_sqrtf(z); } else { s = a; z = s * s; }
+    float r = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * s + s;
+    if (big) { r = r + r; r = PIO2 - r; }
+    return x < 0.0f ? -r : r;
+}
+
 // The HitRecord of an accepted intersection (Hitables.cpp:35-39,102-109, then the instance chain
 // on the way out: :253-260 per rotation, :169 translate).  Recomputed from (prim, t): every step
 // is a deterministic function of the same inputs, so the bits equal the reference's in-place
@@ -311,8 +352,8 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
         h.nrm = scale(h.pos, pr.ga[1]);                         // (pos - 0) / r == * (1.f/r), Vec3.h:85-88
         if (with_uv) {
             f3 p = normalize(h.pos);
-            float theta = atan2f(p.z, p.x);
-            float phi = asinf(p.y);
+            float theta = det_atan2f(p.z, p.x);
+            float phi = det_asinf(p.y);
             const float PI = 3.14159265358979323846f;
             h.u = 1.0f - (theta + PI) / (2.0f * PI);
             h.v = (phi + PI / 2.0f) / PI;

@@ -1,6 +1,6 @@
 """GPU parity: the HIP path through the C ABI against the CPU oracle, on the same seeded inputs.
-Bar: bit-exact (sign of zero excepted where rt_device.h skips identity rotations); sphere u,v use
-atan2f/asinf and are held to 2e-6 absolute."""
+Bar: bit-exact (sign of zero excepted where rt_device.h skips identity rotations), sphere u,v included: atan2f/asinf
+are one float sequence shared with the oracle (det_atan2f / det_asinf)."""
 import os
 
 import numpy as np
@@ -97,7 +97,7 @@ def test_prim_hit(gpu, orc, world):
         for (t0, t1) in ((0.001, FLT_MAX), (0.001, 4.0)):
             g = gpu.prim_hit_batch(p, org, d, t0, t1); o = orc.prim_hit_batch(s, p, org, d, t0, t1)
             assert (o["prim"] >= 0).sum() > 100
-            H.assert_hits_equal(g, o, f"{world} prim {p}", uv_tol=2e-6 if s.kind[p] == capi.PRIM_SPHERE else None)
+            H.assert_hits_equal(g, o, f"{world} prim {p}")
 
 
 @pytest.mark.parametrize("world", ["cornell", "two_boxes", "spheres4", "spheres"])
@@ -113,7 +113,7 @@ def test_world_hit(gpu, orc, world):
     for flags in (0, capi.FLAG_ACCEL_LIST):
         g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags); o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
         assert (o["prim"] >= 0).sum() > 1000
-        H.assert_hits_equal(g, o, f"{world} flags={flags}", uv_tol=2e-6)
+        H.assert_hits_equal(g, o, f"{world} flags={flags}")
     # the library's own BVH (no tree passed): same closest hits as the list
     s.nodes = None
     gpu.upload_scene(s)
@@ -313,7 +313,7 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     # the oracle's restatement of the near-first walk on the library's own tree: whole records, tie winners included
     capi.build_bvh(s)
     o2, st2 = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, orc.FLAG_ACCEL_ORDERED)
-    H.assert_hits_equal(g, o2, "ordered walk vs its restatement", uv_tol=2e-6)
+    H.assert_hits_equal(g, o2, "ordered walk vs its restatement")
     a = gpu.render(w, h, 3, 50, 7, capi.FLAG_ACCEL_ORDERED)
     osum, st3 = orc.trace(s, cam, w, h, 3, 50, 7, orc.FLAG_ACCEL_ORDERED)
     H.assert_bits(a["sum"], osum, "ordered image vs ordered oracle")
@@ -324,7 +324,7 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     gpu.upload_scene(s)
     g1 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0)
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
-    H.assert_hits_equal(g1, o1, "own tree, reference order", uv_tol=2e-6)
+    H.assert_hits_equal(g1, o1, "own tree, reference order")
 
 
 @pytest.mark.parametrize("world", ["cornell", "spheres4", "spheres"])
@@ -348,11 +348,11 @@ def test_axis_parallel_rays(gpu, orc, world):
     d[::7] = np.where(d[::7] == 0, np.float32(-0.0), d[::7])       # both signs of zero
     o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
     assert (o["prim"] >= 0).sum() > 500
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list", uv_tol=2e-6)
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list")
     # the reference's BVH walk culls a ray that only grazes a node box (AABB.cpp:17 uses <=), so it misses some
     # edge and corner hits the list finds; the device does the same in the same cases
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order", uv_tol=2e-6)
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order")
     # near-first: same node boxes under the same rule (objects themselves are not box-culled on a graze, as in the
     # reference), so the same closest t; only the winner of an exact tie may differ
     g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
@@ -373,7 +373,7 @@ def test_million_spheres(gpu, orc):
     d[:, 1] = -np.abs(d[:, 1])                                  # look down at the field
     o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
     assert (o["prim"] > 3).sum() > 200                           # small spheres are being hit, not just the ground
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o, "1M ref order", uv_tol=2e-6)
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o, "1M ref order")
     g2 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
     H.assert_bits(g2["t"], o["t"], "1M near-first t"); assert np.array_equal(g2["prim"], o["prim"])
     w, h = 96, 64
@@ -479,7 +479,7 @@ def test_random_scenes(gpu, orc, seed):
     for flags in (0, capi.FLAG_ACCEL_LIST):
         o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
         assert (o["prim"] >= 0).sum() > 500
-        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags), o, f"seed {seed} flags {flags}", uv_tol=2e-6)
+        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags), o, f"seed {seed} flags {flags}")
     w, h = 72, 48
     for flags in (0, capi.FLAG_ACCEL_LIST):
         g = gpu.render(w, h, 4, 50, seed, flags)

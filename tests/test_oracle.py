@@ -65,6 +65,28 @@ def test_sphere_known_answers():
     assert abs(h["u"][0] - 0.25) < 1e-6 and abs(h["v"][0] - 0.5) < 1e-6
 
 
+def test_sphere_uv_follows_calculateuv_to_a_few_ulp():
+    """CalculateUV (Hitables.cpp:62-78) calls the C runtime's atan2f/asinf; the oracle and the device share one stated float
+    sequence for them instead (det_atan2f / det_asinf).  That sequence must stay a faithful atan2/asin: against the float64
+    formula on the same hit points, u and v differ by a few float ulp at most, over the whole sphere incl. poles and seams."""
+    s = scene.FlatScene(); m = s.lambertian((0.5, 0.5, 0.5)); s.sphere((0.0, 0.0, 0.0), 1.0, m)
+    rng = np.random.default_rng(5)
+    n = 200000
+    tgt = rng.normal(size=(n, 3)); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+    tgt[:6] = [[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]]
+    tgt[6:1000, 2] *= 1e-4                                                      # crowd the u seam (z ~ 0, x < 0 and > 0)
+    tgt[1000:2000, [0, 2]] *= 1e-3                                              # and the poles
+    org = (tgt * 3.0).astype(F); d = (-tgt).astype(F)
+    h = orc.prim_hit_batch(s, 0, org, d, 0.001, FLT_MAX)
+    ok = h["prim"] == 0
+    assert ok.sum() > n - 10
+    pn = (h["pos"][ok] / np.sqrt((h["pos"][ok] ** 2).sum(axis=1, dtype=F))[:, None].astype(F)).astype(np.float64)
+    u = 1.0 - (np.arctan2(pn[:, 2], pn[:, 0]) + np.pi) / (2 * np.pi)
+    v = (np.arcsin(np.clip(pn[:, 1], -1, 1)) + np.pi / 2) / np.pi
+    assert np.abs(h["u"][ok] - u).max() < 4 * 2.0 ** -24 and np.abs(h["v"][ok] - v).max() < 4 * 2.0 ** -24
+    assert h["u"][ok].min() >= 0.0 and h["u"][ok].max() <= 1.0 and h["v"][ok].min() >= 0.0 and h["v"][ok].max() <= 1.0
+
+
 def test_rect_known_answers():
     s = scene.FlatScene(); m = s.lambertian((0.5, 0.5, 0.5))
     s.rect(scene.XZ_RECT, (0.0, 1.0, 0.0), (0, 0, 0), 2.0, 4.0, True, m)          # a = x in [-1,1], b = z in [-2,2], y = 1, normal -y
