@@ -22,7 +22,9 @@
 
 namespace mirt {
 
+#ifndef MIRT_BLOCK
 #define MIRT_BLOCK 256
+#endif
 #ifndef MIRT_BVH_WAVES
 #define MIRT_BVH_WAVES 8   // waves per SIMD the BVH kernels are compiled for (register cap 512 / MIRT_BVH_WAVES)
 #endif
