@@ -760,6 +760,18 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef MIRT_YIELD_WAVES
 #define MIRT_YIELD_WAVES 6   // the yielding walk keeps its walk state live through the shading code
 #endif
+// The kernel's arguments as they lie in the kernarg segment, behind a pointer the compiler cannot see through: what the
+// rare blocks of the loop read (camera, image geometry: ~40 words that only the stash refill needs) is then fetched there
+// with scalar loads instead of living in SGPRs across the whole loop -- where it did not fit, and was spilled to VGPR lanes
+// and read back with v_readlane in the hot path.  TraceArgs is the kernels' only parameter (offset 0 of the segment).
+__device__ __forceinline__ const TraceArgs &late_args()
+{
+    typedef const __attribute__((address_space(4))) unsigned char *KargPtr;
+    KargPtr kp = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const TraceArgs *)kp;
+}
+
 template <int ACCEL, bool PLDS, bool TEX>
 __device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
@@ -866,10 +878,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 if (!exhausted) {
                     const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
                     if (lane < g) {
+                        const TraceArgs &ka = late_args();
                         const uint32_t id = w_next + lane;
-                        const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
+                        const uint32_t sl = id / ka.npix, pl = id - sl * ka.npix;
                         f3 go, gd;
-                        generate_ray(a, tile_pixel(a.pix0 + pl, a.tiles_x, a.width), a.spp0 + sl, go, gd);
+                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.tiles_x, ka.width), ka.spp0 + sl, go, gd);
                         const uint32_t e = cnt + lane;
                         stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
@@ -924,10 +937,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     }
                     const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
                     if (lane < g) {
+                        const TraceArgs &ka = late_args();
                         const uint32_t id = w_next + lane;
-                        const uint32_t sl = id / a.npix, pl = id - sl * a.npix;
+                        const uint32_t sl = id / ka.npix, pl = id - sl * ka.npix;
                         f3 go, gd;
-                        generate_ray(a, tile_pixel(a.pix0 + pl, a.tiles_x, a.width), a.spp0 + sl, go, gd);
+                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.tiles_x, ka.width), ka.spp0 + sl, go, gd);
                         stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
