@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 #include <chrono>
 #include <cstring>
+#include <mutex>
 #include <set>
 #include <string>
 #include <thread>
@@ -44,8 +45,10 @@ struct Rccl {                                                              // th
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::mutex mu;                                                         // contexts of different host threads may arrive here together
     bool load()
     {
+        std::lock_guard<std::mutex> lock(mu);
         if (so) return true;
         so = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!so) so = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);

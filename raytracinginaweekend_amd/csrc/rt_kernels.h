@@ -499,16 +499,20 @@ struct CoopLds { uint32_t pix[64], smp[64], it[64], stg[64]; };
 
 // Is the candidate (the first three words of a Philox block) inside the unit sphere?  The reference decides on
 // the mapped floats (Randomizer.h:43-46: reject while dot(p,p) >= 1), and mapping three words costs 21 f64
-// instructions.  A float estimate of the same coordinates is within 2^-23 of them, so its dot product is within
-// 2e-6 of the exact one: outside a band of 8e-6 around 1 the estimate decides, inside it (about one candidate in
-// 10^5) the exact arithmetic does.  Only the accepted candidate is mapped exactly, once, by its owner.
+// instructions.  Here the squared length is first taken exactly in integers: a word r maps to 2r/(2^32-1) - 1, which is
+// (r - 2^31) / 2^31 to within 5e-10, so S = sum (r_i - 2^31)^2 is the squared length in units of 2^-62 (three 32x32+64
+// multiply-adds, no conversions).  The mapped floats' dot product is within 2e-6 of it: outside a band of 8e-6 around 1
+// the integer decides, inside it (about one candidate in 10^5) the reference's own arithmetic does.  Only the accepted
+// candidate is mapped exactly, once, by its owner.
 __device__ __forceinline__ bool candidate_inside(const uint32_t r[4])
 {
-    const float x = __builtin_fmaf((float)r[0], 0x1p-31f, -1.0f), y = __builtin_fmaf((float)r[1], 0x1p-31f, -1.0f),
-                z = __builtin_fmaf((float)r[2], 0x1p-31f, -1.0f);
-    const float s = (x * x + y * y) + z * z;
-    bool inside = s < 1.0f;
-    if (__builtin_fabsf(s - 1.0f) < 8e-6f) {
+    // sum (r_i - 2^31)^2 = sum r_i^2 - 2^32 * sum r_i + 3 * 2^62, evaluated modulo 2^64 (the true value is <= 3 * 2^62, so
+    // nothing is lost): unsigned multiply-adds, and the other two terms only touch the high word
+    const uint64_t Q = (uint64_t)r[0] * r[0] + (uint64_t)r[1] * r[1] + (uint64_t)r[2] * r[2];
+    const uint32_t hi = (uint32_t)(Q >> 32) - (r[0] + r[1] + r[2]) + 0xC0000000u;   // squared length in units of 2^-30
+    constexpr uint32_t ONE = 0x40000000u, BAND = 8600u;                      // 8600 / 2^30 = 8.0e-6
+    bool inside = hi < ONE;
+    if (hi - (ONE - BAND) < 2u * BAND) {
         const f3 p = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
         inside = !(dot(p, p) >= 1.0f);
     }
