@@ -7,7 +7,7 @@ configuration the metric is quoted on).  `--workload` selects the other BASELINE
     cornell    Cornell box 3-ball 1024x1024 @1024 spp              (configs[1]; list walk, VALU-bound)
     spheres4   ground + three big spheres 200x100 @100 spp          (configs[0]; list walk, VALU-bound)
     spheres    ~485 random spheres 1200x800 @500 spp                (configs[2]; own SAH tree walked near-first)
-    spheres1m  ~1 M spheres 1920x1080 @256 spp                      (configs[3]; same walk in resumable slices)
+    spheres1m  ~1 M spheres 1920x1080 @256 spp                      (configs[3]; same walk)
 
 One step = one complete TraceRay of the workload: every rank renders its slice of the samples-per-pixel range into a
 device-resident float radiance-sum buffer (mirt_render_device), the buffers are summed onto rank 0 with one RCCL reduce,
@@ -213,7 +213,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label} {W}x{H} @{SPP} spp, depth {args.max_depth}, spp-sharded over {world} GPU(s)",
                        "name": args.workload, "seed": args.seed, "objects": int(sc.n_objects),
-                       "accel": f"list ({sc.n_prims} primitives through the scalar cache)" if list_walk else "own binned-SAH tree, near-first walk" + (" in resumable slices" if sc.n_objects >= 65536 else ""),
+                       "accel": f"list ({sc.n_prims} primitives through the scalar cache)" if list_walk else "own binned-SAH tree, near-first wave-synchronous walk",
                        "spp_per_gpu": [sharding.spp_range(r, world, SPP)[1] for r in range(world)],
                        "engine": "persistent (k_trace)" if args.engine == 1 else "wavefront (k_bounce per depth)",
                        "collective": (("RCCL reduce (torch.distributed nccl)" if args.backend == "nccl" else "gloo reduce through host memory (rehearsal)") if world > 1 else "none")},

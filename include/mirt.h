@@ -167,7 +167,10 @@ int         mirt_device_count(void);
  *  "blocks_per_cu"  workgroups per CU of the persistent grid (0 = occupancy query, default)
  *  "walk_yield"     near-first BVH walks in resumable slices: a wave leaves the walk loop once this many of its
  *                   lanes have finished, shades them and resumes the others (1..64); 0: every wave waits for its
- *                   longest walk; -1 (default): 56 for scenes of 65536 objects or more, else 0.  Same image.
+ *                   longest walk; -1 (default): the library's choice, currently 0 at every size.  Same image.
+ *  "leaf_wait"      near-first BVH walks: a lane that reaches an object waits until this many lanes of its wave wait
+ *                   with it (or none has a node left) before the objects are tested, all in one pass (1..64, default 4).
+ *                   Same image: a waiting lane does nothing in between.
  *  "tile_paths"     1 (default): with a BVH walk, the persistent engine hands out pixels in 8x8 tiles rather than
  *                   rows (compact patches of camera rays); 0: rows.  No effect on the image.
  *  "lds_budget", "stack_lds", "lds_mats", "lds_prims"  LDS plan of the next mirt_upload_scene: bytes per workgroup

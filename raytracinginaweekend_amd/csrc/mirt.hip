@@ -76,6 +76,7 @@ struct mirt_ctx {
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
+    uint32_t leaf_wait = MIRT_LEAF_WANT;   // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2)
     int32_t walk_yield = -1;                // near-first walks in slices that end when this many lanes of a wave have finished;
                                             // 0: off, -1 (default): 56 for scenes of 65536 objects or more (+10 % on 1M spheres, -7 % on 485)
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
@@ -191,6 +192,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "lds_prims")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_prims out of range"); c->lds_prims = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "leaf_wait")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "leaf_wait out of range"); c->leaf_wait = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "walk_yield")) { if (value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "walk_yield out of range"); c->walk_yield = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
@@ -337,7 +339,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     c->lds_bytes = used + d.lds_nodes * d.node_bytes;
     c->lds_stack_bytes = d.stack_lds * MIRT_BLOCK * 4u;
     c->sc2.node_bytes = (uint32_t)sizeof(Node2);
-    c->sc2.lds_nodes = std::min<uint32_t>(room_bytes / c->sc2.node_bytes, d.n_nodes);
+    c->sc2.lds_nodes = 0;                                                          // the near-first walks read their nodes from memory (rt_kernels.h closest_bvh2)
     c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
     c->have_scene = true;
     return MIRT_OK;
@@ -457,7 +459,7 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_sum, hipStream_t st, mirt_stats *stats,
                              int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp, const Workspace *fixed = nullptr)
 {
-    const uint32_t yield_want = c->walk_yield >= 0 ? (uint32_t)c->walk_yield : (c->sc.n_objects >= 65536u ? 56u : 0u);
+    const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : 0u;   // -1 (default) = 0: since the walk became wave-synchronous the plain form wins at every size measured
     if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
     const uint64_t npix_total = (uint64_t)p->width * p->height;
     uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
@@ -476,7 +478,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
     TraceArgs a{};
     a.sc = mode >= 2 ? c->sc2 : c->sc; a.cam = c->cam;
-    a.slice_want = yield_want;
+    a.slice_want = yield_want; a.leaf_want = c->leaf_wait;
     uint32_t *counts;
     if (fixed) {
         // nothing is allocated on this path: every size is checked against the fixed scratch instead

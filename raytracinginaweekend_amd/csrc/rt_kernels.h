@@ -25,6 +25,9 @@ namespace mirt {
 #ifndef MIRT_BLOCK
 #define MIRT_BLOCK 256
 #endif
+#ifndef MIRT_LEAF_WANT
+#define MIRT_LEAF_WANT 4u   // closest_bvh2: lanes waiting on a leaf that start an object-test pass (option leaf_wait)
+#endif
 #ifndef MIRT_BVH_WAVES
 #define MIRT_BVH_WAVES 8   // waves per SIMD the BVH kernels are compiled for (register cap 512 / MIRT_BVH_WAVES)
 #endif
@@ -94,13 +97,12 @@ struct LdsView {
     PrimRec *prims; unsigned char *nodes; MatRec *mats; int32_t *stack;
 };
 struct Stack {                       // one lane's traversal stack (see SceneDev::stack_lds)
-    int32_t *lds, *hbm; uint32_t n_lds, n_all, stride, sp;
+    int32_t *lds, *hbm; uint32_t n_lds, stride, sp;   // capacity: tree depth + 1 levels (SceneDev::stack_depth), which no walk exceeds
     __device__ __forceinline__ Stack(const SceneDev &sc, const LdsView &v)
-        : lds(v.stack + threadIdx.x), hbm(sc.spill + (blockIdx.x * MIRT_BLOCK + threadIdx.x)), n_lds(sc.stack_lds), n_all(sc.stack_depth),
+        : lds(v.stack + threadIdx.x), hbm(sc.spill + (blockIdx.x * MIRT_BLOCK + threadIdx.x)), n_lds(sc.stack_lds),
           stride(sc.spill_stride), sp(0) {}
     __device__ __forceinline__ void push(int32_t x)
     {
-        if (sp >= n_all) return;                              // cannot happen: n_all = tree depth + 1
         if (sp < n_lds) lds[sp * MIRT_BLOCK] = x; else hbm[(size_t)(sp - n_lds) * stride] = x;
         ++sp;
     }
@@ -337,52 +339,78 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
     return best;
 }
 
+// The lanes of the wave for which `p` holds (s_and of the compare mask with exec; HIP's __ballot takes an int and costs a
+// select and a compare more)
+__device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+// A wave-uniform kernel argument made a plain SGPR value: without this the compiler re-reads arguments of a hot loop from
+// the kernarg segment in every pass (s_load + s_waitcnt in front of the node fetch) rather than keep them in registers.
+template <class T> __device__ __forceinline__ T sgpr_pin(T x) { asm volatile("" : "+s"(x)); return x; }
+// ... and a pointer so pinned, which the compiler can no longer trace to a kernel argument, is told to be global memory
+// again (it would otherwise be read with flat loads)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) f32x4_t *GlobalF4;
+typedef const __attribute__((address_space(1))) u32x2_t *GlobalU2;
+
 // Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
 // with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
 // current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
 // shrinks early and most of the far subtrees are culled by their box.  The closest t is the same as with
 // the reference's left-first order; only the winner of an exact tie in t can differ.
+// leaf_want: the loop is wave-synchronous -- one node step per pass for every lane that stands on a node -- and a lane that
+// reaches a leaf (an object) WAITS there until `leaf_want` lanes of the wave wait with it, or no lane has a node left to
+// step through; then all waiting lanes test their objects in one pass.  Testing objects whenever any lane stood on one
+// (leaf_want = 1) ran that code -- the sphere test with its square root and divides -- in nearly every pass for the one lane
+// in seven that needed it.  A waiting lane does nothing in between, so the sequence of box tests, object tests and t_max
+// values of every ray is the same for any leaf_want: no result depends on it, nor on which rays share a wave.
 template <bool PLDS>
-__device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max)
+__device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max, uint32_t leaf_want)
 {
     int32_t best = -1;
     Stack stk(sc, v);
     int32_t cur = sc.root;
+    bool act = cur != MIRT_CHILD_NONE;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
+    const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
+    const uint2 *const objs = sgpr_pin(sc.objs);
+    const uint32_t single = sgpr_pin(sc.single);
+    leaf_want = sgpr_pin(leaf_want);
     const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
     for (;;) {
-        if (cur >= 0) {
-            Node2 n;
-            if ((uint32_t)cur < sc.lds_nodes) n = ((const Node2 *)v.nodes)[cur];
-            else {
-                const float4 *g = (const float4 *)(sc.nodes2 + cur);
-                float4 a = g[0], b = g[1], c = g[2], e = g[3];
-                n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
-                n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
-                n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
-            }
+        if (act && cur >= 0) {
+            Node2 n;                                                      // always from memory: staging the top levels in LDS measured neutral, and the
+            const GlobalF4 g = (GlobalF4)(nodes2 + cur);                  // per-lane choice between two address spaces costs flat loads
+            const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
+            n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
+            n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
+            n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
             float tl = 0.0f, tr = 0.0f;
             const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, n.left, tl);
             const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, n.right, tr);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
-                const int32_t far = left_first ? n.right : n.left;
-                stk.push(far);
+                stk.push(left_first ? n.right : n.left);
                 cur = left_first ? n.left : n.right;
-                continue;
-            }
-            if (hl) { cur = n.left; continue; }
-            if (hr) { cur = n.right; continue; }
-        } else if (cur != MIRT_CHILD_NONE) {
-            uint32_t first = (uint32_t)~cur, cnt = 1;
-            if (!sc.single) { uint2 ob = sc.objs[~cur]; first = ob.x; cnt = ob.y; }    // Object::Hit, SimpleObject.cpp:73-83
-            for (uint32_t i = 0; i < cnt; ++i) {
-                float t;
-                if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+            } else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else if (stk.sp == 0) act = false;
+            else cur = stk.pop();
+        }
+        const bool at_leaf = act && cur < 0;
+        const unsigned long long lm = wave_mask(at_leaf);
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(act && cur >= 0) == 0ull)) {
+            if (at_leaf) {
+                uint32_t first = (uint32_t)~cur, cnt = 1;
+                if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    float t;
+                    if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                }
+                if (stk.sp == 0) act = false; else cur = stk.pop();
             }
         }
-        if (stk.sp == 0) break;
-        cur = stk.pop();
+        if (wave_mask(act) == 0ull) break;
     }
     return best;
 }
@@ -395,45 +423,55 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
 struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
 
 template <bool PLDS>
-__device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, bool &act, uint32_t want)
+__device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, bool &act, uint32_t want, uint32_t leaf_want)
 {
     Stack stk(sc, v);
     stk.sp = w.sp;
     int32_t cur = w.cur;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
     const f3 invd = w.invd;
-    const unsigned long long entered = __ballot(act);
+    const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
+    const uint2 *const objs = sgpr_pin(sc.objs);
+    const uint32_t single = sgpr_pin(sc.single);
+    leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
+    const unsigned long long entered = wave_mask(act);
     for (;;) {
-        if (act) {
-            bool down = false;
-            if (cur >= 0) {
-                Node2 n;
-                const float4 *g = (const float4 *)(sc.nodes2 + cur);
-                float4 a = g[0], b = g[1], c = g[2], e = g[3];
-                n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
-                n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
-                n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
-                float tl = 0.0f, tr = 0.0f;
-                const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, w.t_max, n.left, tl);
-                const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, w.t_max, n.right, tr);
-                if (hl && hr) {
-                    const bool left_first = tl <= tr;
-                    stk.push(left_first ? n.right : n.left);
-                    cur = left_first ? n.left : n.right;
-                    down = true;
-                } else if (hl) { cur = n.left; down = true; }
-                else if (hr) { cur = n.right; down = true; }
-            } else if (cur != MIRT_CHILD_NONE) {
-                uint32_t first = (uint32_t)~cur, cnt = 1;
-                if (!sc.single) { uint2 ob = sc.objs[~cur]; first = ob.x; cnt = ob.y; }    // Object::Hit, SimpleObject.cpp:73-83
-                for (uint32_t i = 0; i < cnt; ++i) {
-                    float t;
-                    if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
-                }
-            }
-            if (!down) { if (stk.sp == 0) act = false; else cur = stk.pop(); }
+        if (act && cur >= 0) {
+            Node2 n;
+            const GlobalF4 g = (GlobalF4)(nodes2 + cur);
+            const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
+            n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
+            n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
+            n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
+            float tl = 0.0f, tr = 0.0f;
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, w.t_max, n.left, tl);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, w.t_max, n.right, tr);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stk.push(left_first ? n.right : n.left);
+                cur = left_first ? n.left : n.right;
+            } else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else if (stk.sp == 0) act = false;
+            else cur = stk.pop();
         }
-        const unsigned long long still = __ballot(act);
+        // lanes on a leaf wait for company (closest_bvh2); a slice may end while they wait: the leaf is then the lane's `cur`
+        const bool at_leaf = act && cur < 0;
+        const unsigned long long lm = wave_mask(at_leaf);
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(act && cur >= 0) == 0ull)) {
+            if (at_leaf) {
+                if (cur != MIRT_CHILD_NONE) {
+                    uint32_t first = (uint32_t)~cur, cnt = 1;
+                    if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t;
+                        if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                    }
+                }
+                if (stk.sp == 0) act = false; else cur = stk.pop();
+            }
+        }
+        const unsigned long long still = wave_mask(act);
         if (still == 0ull || (uint32_t)__popcll(entered & ~still) >= want) break;
     }
     w.cur = cur; w.sp = stk.sp;
@@ -634,7 +672,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
             const float t_min = 0.001f;
             int32_t best;
             if (EXP_ON(8)) { best = (int32_t)(lane % 9u); t_max = 1.0f + 0.01f * lane; }
-            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
+            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max, MIRT_LEAF_WANT)
                       : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
@@ -730,6 +768,7 @@ struct TraceArgs {
     uint32_t max_depth, flags, k0, k1;
     uint32_t tiles_x;              // > 0: path ids run over 8x8 pixel tiles (tile_pixel), tiles_x = width / 8
     uint32_t slice_want;           // ACCEL 3: finished walks that end a slice (bvh2_slice)
+    uint32_t leaf_want;            // ACCEL 2, 3: lanes waiting on a leaf that start an object-test pass (closest_bvh2)
     // second stream (MIRT_DEFER_MD, list walk): per-wave queues in HBM, plane-major.  mdq: MDQ_PLANES float4 planes of MDQ_CAP
     // parked metal/dielectric vertices; rdy: RDY_PLANES planes of RDY_CAP rays ready to be traced.  NULL: not used.
     float4 *mdq, *rdy;
@@ -979,7 +1018,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     ws.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
                     walking = true;
                 }
-                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, walking, a.slice_want);
+                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, walking, a.slice_want, a.leaf_want);
             }
             ready = live && !walking;
         }
@@ -988,7 +1027,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             const float t_min = 0.001f;
             int32_t best;
             if constexpr (ACCEL == 3) { best = ws.best; t_max = ws.t_max; }
-            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max)
+            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max, a.leaf_want)
                       : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
@@ -1158,7 +1197,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_world_hit_batch(SceneDev sc, con
     for (uint32_t i = blockIdx.x * MIRT_BLOCK + threadIdx.x; i < nray; i += gridDim.x * MIRT_BLOCK) {
         f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
         float tm = t_max;
-        int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm)
+        int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm, MIRT_LEAF_WANT)
                      : (ACCEL == 1 ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm));
         Hit h;
         const PrimRec *P = PLDS ? lv.prims : sc.prims;

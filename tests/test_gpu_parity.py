@@ -257,6 +257,33 @@ def test_yielding_walk(gpu, orc):
         gpu.set_option("walk_yield", -1); gpu.set_option("max_paths", 1 << 30)
 
 
+def test_leaf_wait_changes_no_bit(gpu, orc):
+    """Option leaf_wait (rt_kernels.h closest_bvh2 / bvh2_slice): how many lanes of a wave must stand on an object before
+    the wave tests objects.  A waiting lane does nothing, so every ray sees the same boxes, objects and t_max in the same
+    order whatever the setting: hit records incl. tie winners equal the ordered oracle's, images equal bit for bit, plain and
+    yielding walk alike."""
+    s, cam = scene.spheres_world(64 / 48)
+    capi.build_bvh(s)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    w, h = 64, 48
+    org, d = H.ray_batch(4096, 77, center=(0.0, 1.0, 0.0), extent=12.0)
+    o_hits, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, orc.FLAG_ACCEL_ORDERED)
+    osum, ost = orc.trace(s, cam, w, h, 5, 50, 9, orc.FLAG_ACCEL_ORDERED)
+    try:
+        for lw in (1, 2, 4, 17, 64):
+            gpu.set_option("leaf_wait", lw)
+            for wy in (0, 40):
+                gpu.set_option("walk_yield", wy)
+                g = gpu.render(w, h, 5, 50, 9, capi.FLAG_ACCEL_ORDERED)
+                H.assert_bits(g["sum"], osum, f"leaf_wait={lw} walk_yield={wy}")
+                assert g["stats"].rays == ost.rays
+        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED), o_hits, "hit batch, ordered walk")
+        with pytest.raises(capi.MirtError):
+            gpu.set_option("leaf_wait", 0)
+    finally:
+        gpu.set_option("leaf_wait", 4); gpu.set_option("walk_yield", -1)
+
+
 def test_depth_limits(gpu, orc):
     s, cam = scene.cornell_box(1.0)
     gpu.upload_scene(s); gpu.set_camera(cam)
