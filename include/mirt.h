@@ -175,7 +175,7 @@ int         mirt_device_count(void);
  *                   rows (compact patches of camera rays); 0: rows.  No effect on the image.
  *  "lds_budget", "stack_lds", "lds_mats", "lds_prims"  LDS plan of the next mirt_upload_scene: bytes per workgroup
  *                   up to which the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS
- *                   (default 2, the rest spills to HBM), largest material table staged (default 1024 bytes),
+ *                   (default 4, the rest spills to HBM), largest material table staged (default 1024 bytes),
  *                   largest primitive table staged (default 4096 bytes; such scenes are walked as a list under
  *                   MIRT_FLAG_ACCEL_AUTO when they have at most 32 primitives) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
@@ -204,7 +204,7 @@ int mirt_render_device(mirt_ctx *ctx, const mirt_render_params *p, float *d_sum_
 /* mirt_render_device for callers that cannot allocate.  No counterpart in the reference (its TraceRay new[]s its
  * own buffer, HomemadeRayTracer.cpp:103): this entry point is for code under HIP-graph capture, tight serving loops
  * and harnesses that forbid hipMalloc.  Same kernels, same arguments (no statistics), same bits in d_sum_rgb; the
- * radiance slots, claim counters and the HBM part of the traversal stacks live in a fixed 64 MiB array in the
+ * radiance slots, claim counters and the HBM part of the traversal stacks live in a fixed 56 MiB array in the
  * library's device image (one copy per GPU, held until the process ends) instead of hipMalloc'ed buffers, and the
  * call makes no hipMalloc / hipFree / allocating library call.  Limits (MIRT_ERR_ARG with a message beyond them):
  * batches of 2 Mi paths, at most 3971 batches per call (width*height*spp_count <= ~8.3e9), 31 MiB of stack spill

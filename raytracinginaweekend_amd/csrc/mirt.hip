@@ -35,11 +35,11 @@ struct DevBuf {
 // library runs on holds its own copy until the process ends.  In host code the array's NAME is only a handle for
 // hipGetSymbolAddress: the address kernels and hipMemsetAsync get is g_scratch_ptr[device], looked up once per
 // device in mirt_create with that device current.
-constexpr size_t SCRATCH_RAD_PATHS = 2u << 20;                       // 2 Mi paths per batch: 32 MiB of float4 slots
-constexpr size_t SCRATCH_RAD_BYTES = SCRATCH_RAD_PATHS * sizeof(float4);
+constexpr size_t SCRATCH_RAD_PATHS = 2u << 20;                       // 2 Mi paths per batch: 24 MiB of 12-byte slots
+constexpr size_t SCRATCH_RAD_BYTES = SCRATCH_RAD_PATHS * sizeof(RadSlot);
 constexpr size_t SCRATCH_COUNTS_BYTES = 1u << 20;                    // 66 words per batch: up to 3971 batches per call
 constexpr size_t SCRATCH_SPILL_BYTES = 31u << 20;                    // traversal-stack levels beyond the LDS part
-constexpr size_t SCRATCH_BYTES = SCRATCH_RAD_BYTES + SCRATCH_COUNTS_BYTES + SCRATCH_SPILL_BYTES;   // 64 MiB
+constexpr size_t SCRATCH_BYTES = SCRATCH_RAD_BYTES + SCRATCH_COUNTS_BYTES + SCRATCH_SPILL_BYTES;   // 56 MiB
 constexpr int SCRATCH_MAX_DEVICES = 64;
 __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
 unsigned char *g_scratch_ptr[SCRATCH_MAX_DEVICES];                   // written under g_scratch_mu, never cleared
@@ -47,7 +47,7 @@ std::mutex g_scratch_mu;
 
 // Where one render keeps its scratch: hipMalloc'ed buffers of the context (grown on demand) or a carving of `scratch`.
 struct Workspace {
-    float4 *rad; size_t rad_paths;
+    RadSlot *rad; size_t rad_paths;
     uint32_t *counts; size_t counts_bytes;
     int32_t *spill; size_t spill_bytes;
 };
@@ -81,7 +81,7 @@ struct mirt_ctx {
                                             // 0: off, -1 (default): 56 for scenes of 65536 objects or more (+10 % on 1M spheres, -7 % on 485)
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
-    uint32_t stack_lds = 2;                // traversal-stack levels kept in LDS (1 KiB each); likewise
+    uint32_t stack_lds = 4;                // traversal-stack levels kept in LDS (1 KiB each; 4 measured best with the wave-synchronous walk, 1-8 within 3 %); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
@@ -493,9 +493,9 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         a.rad = fixed->rad; counts = fixed->counts;
         a.sc.spill = fixed->spill; a.sc.spill_stride = max_grid * MIRT_BLOCK;
     } else {
-        if (c->d_rad.ensure(capq * sizeof(float4)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
+        if (c->d_rad.ensure(capq * sizeof(RadSlot)) || c->d_counts.ensure(n_batches * per_batch * sizeof(uint32_t)))
             return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the radiance slots failed (lower the max_paths option)");
-        a.rad = (float4 *)c->d_rad.p; counts = (uint32_t *)c->d_counts.p;
+        a.rad = (RadSlot *)c->d_rad.p; counts = (uint32_t *)c->d_counts.p;
         if (bind_spill(c, a.sc, max_grid)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed");
     }
     HIPCHK(c, hipMemsetAsync(counts, 0, n_batches * per_batch * sizeof(uint32_t), st));
@@ -532,7 +532,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             launch_trace(c, mode, a, grid, st);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch + 1], st));
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
-                               (const float4 *)a.rad, d_sum, pix0, np, ns, one_spp ? 1u : 0u, a.tiles_x, a.width);
+                               (const RadSlot *)a.rad, d_sum, pix0, np, ns, one_spp ? 1u : 0u, a.tiles_x, a.width);
         }
     }
     HIPCHK(c, hipGetLastError());
@@ -596,7 +596,7 @@ extern "C" int mirt_render_device_noalloc(mirt_ctx *c, const mirt_render_params 
     if (spp_count == 0) return MIRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     Workspace w;
-    w.rad = (float4 *)c->scratch_dev; w.rad_paths = SCRATCH_RAD_PATHS;
+    w.rad = (RadSlot *)c->scratch_dev; w.rad_paths = SCRATCH_RAD_PATHS;
     w.counts = (uint32_t *)(c->scratch_dev + SCRATCH_RAD_BYTES); w.counts_bytes = SCRATCH_COUNTS_BYTES;
     w.spill = (int32_t *)(c->scratch_dev + SCRATCH_RAD_BYTES + SCRATCH_COUNTS_BYTES); w.spill_bytes = SCRATCH_SPILL_BYTES;
     return render_persistent(c, p, d_sum, (hipStream_t)stream, nullptr, accel_mode(c, p->flags), spp_begin, spp_count, one_spp, &w);
@@ -641,7 +641,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const uint64_t cap_slots = n_chunks_max * chunk;
     if (cap_slots > 0xFFFF0000ull) return fail(c, MIRT_ERR_ARG, "mirt_render_device: ray queue larger than 2^32 slots (lower max_paths)");
 
-    if (c->d_queues.ensure(2 * 3 * cap_slots * sizeof(float4)) || c->d_rad.ensure(capq * sizeof(float4)) ||
+    if (c->d_queues.ensure(2 * 3 * cap_slots * sizeof(float4)) || c->d_rad.ensure(capq * sizeof(RadSlot)) ||
         c->d_counts.ensure(((size_t)n_batches * n_depth * 3 + 1) * sizeof(uint32_t)) || c->d_len.ensure(2 * n_chunks_max * sizeof(uint32_t)))
         return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the ray queues failed (lower the max_paths option)");
     PathQ q[2] = { carve_queue((float4 *)c->d_queues.p, cap_slots), carve_queue((float4 *)c->d_queues.p + 3 * cap_slots, cap_slots) };
@@ -654,7 +654,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
 
     BounceArgs a{};
     a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam;
-    if (bind_spill(c, a.sc, grid_max)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed"); a.rad = (float4 *)c->d_rad.p;
+    if (bind_spill(c, a.sc, grid_max)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed"); a.rad = (RadSlot *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.chunk_shift = chunk_shift; a.cap_slots = (uint32_t)cap_slots; a.overflow = overflow;
@@ -688,7 +688,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
                 if (p->flags & MIRT_FLAG_NORMAL_DISPLAY) break;      // every path ends at its first vertex
             }
             hipLaunchKernelGGL(k_accumulate, dim3((np + MIRT_BLOCK - 1) / MIRT_BLOCK), dim3(MIRT_BLOCK), 0, st,
-                               (const float4 *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u, 0u, p->width);
+                               (const RadSlot *)c->d_rad.p, d_sum, pix0, np, ns, one_spp ? 1u : 0u, 0u, p->width);
         }
     }
     HIPCHK(c, hipGetLastError());

@@ -38,6 +38,17 @@ struct PathQ {
     float4 *p0, *p1, *p2;
 };
 
+// A path's radiance slot: three floats, 12 bytes.  Written once, by the lane that ends the path; read once, by k_accumulate,
+// which is bound by HBM -- so the slot carries no padding word.
+struct RadSlot { float r, g, b; };
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
+typedef f32x3_t f32x3_a4 __attribute__((aligned(4)));
+__device__ __forceinline__ void store_rad(RadSlot *rad, size_t slot, f3 v)
+{
+    f32x3_t x; x.x = v.x; x.y = v.y; x.z = v.z;
+    *(f32x3_a4 *)(rad + slot) = x;
+}
+
 struct SceneDev {
     const PrimRec *prims;  uint32_t n_prims;
     const PrimRec *lprims; uint32_t lend[4];     // the list walk's copy, sorted by class (closest_list); .mat = index in `prims`
@@ -79,7 +90,7 @@ struct BounceArgs {
     uint32_t *overflow;            // set if a reservation would pass cap_slots (never, by the host's bound)
     uint32_t chunk_shift, cap_slots;
     uint32_t n_first;
-    float4 *rad;
+    RadSlot *rad;
     SceneDev sc;
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
@@ -705,7 +716,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
         }
         if (active && done && !EXP_ON(1)) {
             uint32_t slot = (sample - a.spp0) * a.npix + (pixel - a.pix0);
-            a.rad[slot] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            store_rad(a.rad, slot, radiance);
         }
         // -------- compaction: wave ballot + prefix popcount; slots come from the workgroup's open chunk
         const unsigned long long m = __ballot(alive);
@@ -758,7 +769,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
 // radiance slot per path touches HBM, and one launch serves a whole batch.
 // Every path's arithmetic and Philox keys are those of k_bounce, so the two engines give identical images.
 struct TraceArgs {
-    float4 *rad;
+    RadSlot *rad;
     uint32_t *cursor;              // next unclaimed path id of the batch
     uint32_t *hist;                // [0..63] paths ended at depth d (63: at 63 or deeper), [64] vertices beyond depth 63
     uint32_t n_paths, claim;       // claim: path ids taken per atomic (multiple of 64)
@@ -870,7 +881,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         }
         if (dead) {                                                   // absorbed by the metal: thr * (0,0,0), :173
             const f3 z = scale(sthr, 0.0f);
-            a.rad[spid] = make_float4(z.x, z.y, z.z, 0.0f);
+            store_rad(a.rad, spid, z);
             atomicAdd(&s_hist[sdepth < 63u ? sdepth : 63u], 1u);
             if (sdepth > 63u) atomicAdd(&s_hist[64], sdepth - 63u);
         }
@@ -1083,7 +1094,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         }
         if (parked) live = false;
         if (ready && done) {
-            if (!(MIRT_TEXP & 8)) a.rad[pid] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+            if (!(MIRT_TEXP & 8)) store_rad(a.rad, pid, radiance);
             atomicAdd(&s_hist[depth < 63u ? depth : 63u], 1u);
             if (depth > 63u) atomicAdd(&s_hist[64], depth - 63u);
             live = false;
@@ -1104,7 +1115,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK, ACCEL == 3 ? MIRT_YIELD_WAVES : MI
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
-__global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const float4 *__restrict__ rad, float *__restrict__ sum,
+__global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const RadSlot *__restrict__ rad, float *__restrict__ sum,
                                                            uint32_t pix0, uint32_t npix, uint32_t nsamp, uint32_t overwrite,
                                                            uint32_t tiles_x, uint32_t width)
 {
@@ -1112,19 +1123,18 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_accumulate(const float4 *__restr
     if (pl >= npix) return;
     float *s = sum + 3 * (size_t)tile_pixel(pix0 + pl, tiles_x, width);
     f3 acc = overwrite ? mk(0.0f, 0.0f, 0.0f) : mk(s[0], s[1], s[2]);
-    if (overwrite) { float4 r = rad[pl]; acc = mk(r.x, r.y, r.z); }
+    const f32x3_a4 *p = (const f32x3_a4 *)(rad + pl);              // sample k of this pixel: k * npix slots further on
+    if (overwrite) { const f32x3_t r = p[0]; acc = mk(r.x, r.y, r.z); }
     else {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 *p = (const f32x4 *)rad + pl;
         uint32_t k = 0;
         for (; k + 8u <= nsamp; k += 8u) {                         // eight loads in flight, then the ordered adds; read once: no reuse
-            f32x4 r[8];
+            f32x3_t r[8];
 #pragma unroll
-            for (uint32_t j = 0; j < 8u; ++j) r[j] = __builtin_nontemporal_load(p + (size_t)(k + j) * npix);
+            for (uint32_t j = 0; j < 8u; ++j) r[j] = __builtin_nontemporal_load((const f32x3_a4 *)((const RadSlot *)p + (size_t)(k + j) * npix));
 #pragma unroll
             for (uint32_t j = 0; j < 8u; ++j) acc = acc + mk(r[j].x, r[j].y, r[j].z);
         }
-        for (; k < nsamp; ++k) { f32x4 r = p[(size_t)k * npix]; acc = acc + mk(r.x, r.y, r.z); }
+        for (; k < nsamp; ++k) { const f32x3_t r = *(const f32x3_a4 *)((const RadSlot *)p + (size_t)k * npix); acc = acc + mk(r.x, r.y, r.z); }
     }
     s[0] = acc.x; s[1] = acc.y; s[2] = acc.z;
 }
