@@ -41,7 +41,7 @@ BYTES_BOX, BYTES_SPHERE = 32.0, 16.0            # SURVEY 8(d), configs[3]: bytes
 # fp32 (157.3 TFLOP/s is the same rate counted as FMAs); contraction is off on this path, so one flop = one lane-op.
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-RAD_BYTES = 16.0                # one float4 per finished path, written once (k_trace), read once (k_accumulate)
+RAD_BYTES = 12.0                # one 12-byte slot (three floats) per finished path, written once (k_trace), read once (k_accumulate)
 PATH_STATE_BYTES = 44.0         # wavefront engine only
 
 WORKLOADS = {
