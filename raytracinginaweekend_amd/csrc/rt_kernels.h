@@ -773,6 +773,10 @@ struct TraceArgs {
     uint32_t *cursor;              // next unclaimed path id of the batch
     uint32_t *hist;                // [0..63] paths ended at depth d (63: at 63 or deeper), [64] vertices beyond depth 63
     uint32_t n_paths, claim;       // claim: path ids taken per atomic (multiple of 64)
+    // Every wave of the grid starts with path ids of its own, [w * own_paths, (w + 1) * own_paths) for wave w, and claims
+    // only after those: the ids from first_claim = (waves of the grid) * own_paths on.  One atomic word hands out ~90 M
+    // claims a second, which a small render (2 M paths in claims of 64) would otherwise spend most of its time on.
+    uint32_t own_paths, first_claim;
     SceneDev sc;
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
@@ -836,7 +840,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
     __shared__ uint32_t s_hist[65];
 
-    if ((uint64_t)blockIdx.x * a.claim >= a.n_paths) return;        // more workgroups than claims (uniform)
+    if (a.own_paths == 0u && (uint64_t)blockIdx.x * a.claim >= a.n_paths) return;   // more workgroups than claims (uniform)
     const LdsView lv = lds_view(a.sc, smem);
     if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
     lds_stage(a.sc, lv);                                            // ends with a barrier
@@ -845,7 +849,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 
     // wave-uniform bookkeeping
     uint32_t cnt = 0;                       // rays in the stash
-    uint32_t w_next = 0, w_end = 0;         // claimed, not yet generated path ids
+    uint32_t w_next = (blockIdx.x * (MIRT_BLOCK / 64) + wave) * a.own_paths, w_end = w_next + a.own_paths;   // owned or claimed, not yet generated path ids
     bool exhausted = false;
     // the lane's path
     bool live = false;
@@ -924,7 +928,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             if (cnt + 64u <= STASH_N && !exhausted) {
                 if (w_next == w_end) {
                     uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(a.cursor, a.claim);
+                    if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
                     b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
                     if (b >= a.n_paths) exhausted = true;
                     else { w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim; }
@@ -984,7 +988,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     if (served == n_idle || exhausted) break;
                     if (w_next == w_end) {
                         uint32_t b = 0;
-                        if (lane == 0) b = atomicAdd(a.cursor, a.claim);
+                        if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
                         b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
                         if (b >= a.n_paths) { exhausted = true; break; }
                         w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
