@@ -530,13 +530,14 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, max_grid);
             // Small launches (claims of 64: under 4096 paths per wave) would be bound by the claim counter -- one atomic word hands
             // out ~90 M claims a second, the list walk ends 140 M claims' worth of paths -- so there three quarters of a wave's fair
-            // share are its own from the start and only the rest is claimed (4-sphere 200x100@100: 0.59 -> 0.36 ms, Cornell
-            // 512^2@64: 3.39 -> 2.76 ms).  Larger launches keep claiming everything: ids are contiguous pixels of one sample, and
-            // waves that own whole image rows get unequal work (Cornell 1024^2: @32 4.2 -> 4.6 ms with 2048 own ids, @512 56 -> 73 ms
-            // with three quarters)
+            // share are its own from the start, dealt in chunks of 64 ids round-robin over the waves (TraceArgs::own_chunks), and
+            // only the rest is claimed (4-sphere 200x100@100: 0.59 -> 0.37 ms, Cornell 1024^2@16: 3.40 -> 2.53 ms).  Larger launches
+            // keep claiming everything: waves do not advance at equal speed (Cornell 1024^2@512 with equal shares for all, however
+            // dealt and at any grid size: 56 -> 75 ms), and claims are what evens that out.
             const uint64_t grid_waves = (uint64_t)grid * (MIRT_BLOCK / 64);
-            a.own_paths = a.claim == 64u ? (uint32_t)((a.n_paths / grid_waves * 3 / 4) & ~63ull) : 0u;
-            a.first_claim = (uint32_t)(grid_waves * a.own_paths);
+            a.grid_waves = (uint32_t)grid_waves;
+            a.own_chunks = a.claim == 64u ? (uint32_t)(a.n_paths / grid_waves / 64 * 6 / 8) : 0u;
+            a.first_claim = (uint32_t)(grid_waves * a.own_chunks * 64);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch], st));
             launch_trace(c, mode, a, grid, st);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch + 1], st));

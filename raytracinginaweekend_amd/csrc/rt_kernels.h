@@ -773,10 +773,12 @@ struct TraceArgs {
     uint32_t *cursor;              // next unclaimed path id of the batch
     uint32_t *hist;                // [0..63] paths ended at depth d (63: at 63 or deeper), [64] vertices beyond depth 63
     uint32_t n_paths, claim;       // claim: path ids taken per atomic (multiple of 64)
-    // Every wave of the grid starts with path ids of its own, [w * own_paths, (w + 1) * own_paths) for wave w, and claims
-    // only after those: the ids from first_claim = (waves of the grid) * own_paths on.  One atomic word hands out ~90 M
-    // claims a second, which a small render (2 M paths in claims of 64) would otherwise spend most of its time on.
-    uint32_t own_paths, first_claim;
+    // Every wave of the grid first works through chunks of 64 path ids that are its own without asking: chunk k of wave w is
+    // ids [(k * grid_waves + w) * 64, +64) for k < own_chunks -- dealt round-robin, so that each wave's share is spread over
+    // the whole batch (contiguous shares are contiguous image rows, and rows differ in work).  Only the ids from
+    // first_claim = grid_waves * own_chunks * 64 on are claimed from the cursor, which balances the end of the launch.
+    // One atomic word hands out ~90 M claims a second; a launch that claimed everything in units of 64 was bound by it.
+    uint32_t own_chunks, grid_waves, first_claim;
     SceneDev sc;
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
@@ -840,7 +842,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
     __shared__ uint32_t s_hist[65];
 
-    if (a.own_paths == 0u && (uint64_t)blockIdx.x * a.claim >= a.n_paths) return;   // more workgroups than claims (uniform)
+    if (a.own_chunks == 0u && (uint64_t)blockIdx.x * a.claim >= a.n_paths) return;   // more workgroups than claims (uniform)
     const LdsView lv = lds_view(a.sc, smem);
     if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
     lds_stage(a.sc, lv);                                            // ends with a barrier
@@ -849,7 +851,22 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
 
     // wave-uniform bookkeeping
     uint32_t cnt = 0;                       // rays in the stash
-    uint32_t w_next = (blockIdx.x * (MIRT_BLOCK / 64) + wave) * a.own_paths, w_end = w_next + a.own_paths;   // owned or claimed, not yet generated path ids
+    uint32_t w_next = 0, w_end = 0;         // owned or claimed, not yet generated path ids
+    uint32_t own_k = 0;                     // chunks of its own the wave has started
+    // the next run of path ids for this wave (w_next == w_end): its next own chunk, else a claim; false when the batch is handed out
+    auto next_range = [&]() -> bool {
+        if (own_k < a.own_chunks) {
+            w_next = (own_k * a.grid_waves + (blockIdx.x * (MIRT_BLOCK / 64) + wave)) * 64u; w_end = w_next + 64u;
+            ++own_k;
+            return true;
+        }
+        uint32_t b = 0;
+        if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= a.n_paths) return false;
+        w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
+        return true;
+    };
     bool exhausted = false;
     // the lane's path
     bool live = false;
@@ -926,13 +943,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         if constexpr (BIG_STASH) {
             // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
             if (cnt + 64u <= STASH_N && !exhausted) {
-                if (w_next == w_end) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    if (b >= a.n_paths) exhausted = true;
-                    else { w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim; }
-                }
+                if (w_next == w_end && !next_range()) exhausted = true;
                 if (!exhausted) {
                     const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
                     if (lane < g) {
@@ -986,13 +997,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     cnt -= take; served += take;
                     wave_lds_sync();                                // entries read above may be rewritten below
                     if (served == n_idle || exhausted) break;
-                    if (w_next == w_end) {
-                        uint32_t b = 0;
-                        if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
-                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                        if (b >= a.n_paths) { exhausted = true; break; }
-                        w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
-                    }
+                    if (w_next == w_end && !next_range()) { exhausted = true; break; }
                     const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
                     if (lane < g) {
                         const TraceArgs &ka = late_args();
