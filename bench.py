@@ -67,8 +67,8 @@ def make_scene(name, aspect):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)

@@ -508,6 +508,14 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         a.mdq = (float4 *)c->d_mdq.p; a.rdy = (float4 *)c->d_rdy.p;
     }
 #endif
+#if (MIRT_TEXP & 16)
+    {   // schedule dump build: two float4 per wave of the grid (trace_body), written to $MIRT_WAVE_DUMP after the render
+        const size_t waves = (size_t)max_grid * (MIRT_BLOCK / 64);
+        if (c->d_mdq.ensure(waves * 2 * sizeof(float4))) return fail(c, MIRT_ERR_NOMEM, "wave dump buffer");
+        HIPCHK(c, hipMemsetAsync(c->d_mdq.p, 0, waves * 2 * sizeof(float4), st));
+        a.mdq = (float4 *)c->d_mdq.p;
+    }
+#endif
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, st));
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
@@ -550,6 +558,13 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         HIPCHK(c, hipEventRecord(c->ev1, st));
         HIPCHK(c, hipStreamSynchronize(st));
         float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+#if (MIRT_TEXP & 16)
+        if (const char *path = getenv("MIRT_WAVE_DUMP")) {
+            std::vector<uint32_t> w((size_t)max_grid * (MIRT_BLOCK / 64) * 8);
+            HIPCHK(c, hipMemcpy(w.data(), c->d_mdq.p, w.size() * 4, hipMemcpyDeviceToHost));
+            if (FILE *f = fopen(path, "wb")) { fwrite(w.data(), 4, w.size(), f); fclose(f); }
+        }
+#endif
         std::vector<uint32_t> h(n_batches * per_batch);
         HIPCHK(c, hipMemcpy(h.data(), counts, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
         stats->device_ms = ms; stats->bounce_launches = n_batches; stats->batches = n_batches;

@@ -853,6 +853,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     uint32_t cnt = 0;                       // rays in the stash
     uint32_t w_next = 0, w_end = 0;         // owned or claimed, not yet generated path ids
     uint32_t own_k = 0;                     // chunks of its own the wave has started
+    uint32_t x_made = 0, x_iters = 0;       // MIRT_TEXP & 16: per-wave schedule dump (tools/wave_dump.py)
+    const unsigned long long x_t0 = (MIRT_TEXP & 16) ? wall_clock64() : 0ull;
     // the next run of path ids for this wave (w_next == w_end): its next own chunk, else a claim; false when the batch is handed out
     auto next_range = [&]() -> bool {
         if (own_k < a.own_chunks) {
@@ -860,6 +862,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             ++own_k;
             return true;
         }
+        // (Guided self-scheduling -- claims that shrink towards the end of the batch -- was measured and lost: waves of one SIMD
+        // advance at very different speeds, 0.3 to 2.7 paths/us within one launch (tools/wave_dump.py: the oldest wave is served
+        // first), and the last exits of a 28.8 ms launch are spread over 1.2 ms; but shrinking to 64 ids cost 5 ms at the claim
+        // counter, and floors of 256..1024 ids left the time where it was.)
         uint32_t b = 0;
         if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
         b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
@@ -956,7 +962,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
-                    w_next += g; cnt += g;
+                    w_next += g; cnt += g; x_made += g;
                     wave_lds_sync();
                 }
             }
@@ -1008,12 +1014,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
-                    w_next += g; cnt = g;
+                    w_next += g; cnt = g; x_made += g;
                     wave_lds_sync();
                 }
             }
         }
         const unsigned long long live_now = __ballot(live);
+        if (MIRT_TEXP & 16) ++x_iters;
         if (live_now == 0ull) {                                     // pool exhausted, stash empty, every path ended
             if constexpr (DEFER) { if (q_cnt != 0u) { service(q_cnt < 64u ? q_cnt : 64u); continue; } if (r_cnt != 0u) continue; }
             break;
@@ -1109,6 +1116,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             live = false;
         }
         if (ready && !retry) ++depth;
+    }
+    if ((MIRT_TEXP & 16) && a.mdq && lane == 0) {
+        const unsigned long long t1 = wall_clock64();
+        const uint32_t gw = blockIdx.x * (MIRT_BLOCK / 64) + wave;
+        a.mdq[2 * gw] = make_float4(__uint_as_float(x_made), __uint_as_float(x_iters), __uint_as_float(__builtin_amdgcn_s_getreg(63492)), __uint_as_float(__builtin_amdgcn_s_getreg(63508)));
+        a.mdq[2 * gw + 1] = make_float4(__uint_as_float((uint32_t)x_t0), __uint_as_float((uint32_t)(x_t0 >> 32)), __uint_as_float((uint32_t)t1), __uint_as_float((uint32_t)(t1 >> 32)));
     }
     __syncthreads();
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
