@@ -532,9 +532,10 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
             a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_paths = np * ns;
             a.cursor = counts + batch * per_batch; a.hist = a.cursor + 1;
-            // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim
+            // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim.  At most 512 ids: what a wave
+            // still holds when the cursor runs dry is the tail of the launch (exits spread over 0.72 ms with 2048, 0.65 with 512)
             const uint64_t waves = (uint64_t)max_grid * (MIRT_BLOCK / 64);
-            a.claim = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
+            a.claim = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, max_grid);
             // Small launches (claims of 64: under 4096 paths per wave) would be bound by the claim counter -- one atomic word hands
             // out ~90 M claims a second, the list walk ends 140 M claims' worth of paths -- so there three quarters of a wave's fair
