@@ -207,6 +207,28 @@ def test_batching_and_ranges(gpu, orc):
     H.assert_bits(part, osum, "oracle ranges")
 
 
+def test_launch_with_own_path_ids(gpu, orc):
+    """Launches of 1 M .. 29 M paths give every wave of the persistent grid chunks of 64 path ids of its own before it
+    starts claiming (mirt.hip render_persistent, TraceArgs::own_chunks).  Who traces a path changes nothing: the image of
+    such a launch equals the oracle's bit for bit, for the list walk and for a BVH walk with tiled path ids, and also when
+    the batches cut it into launches that take the other route (all ids claimed)."""
+    for mk, w, h, spp, flags, oflags in ((lambda: scene.cornell_box(1.0), 512, 512, 6, capi.FLAG_ACCEL_LIST, capi.FLAG_ACCEL_LIST),
+                                         (lambda: scene.spheres_world(480 / 320), 480, 320, 8, capi.FLAG_ACCEL_ORDERED, orc.FLAG_ACCEL_ORDERED)):
+        s, cam = mk()
+        if flags != capi.FLAG_ACCEL_LIST:
+            capi.build_bvh(s)
+        gpu.upload_scene(s); gpu.set_camera(cam)
+        osum, ost = orc.trace(s, cam, w, h, spp, 50, 77, oflags)
+        try:
+            for max_paths in (1 << 30, 300000):                              # one launch of 1.2 - 1.6 M paths; batches of 0.3 M (no own ids)
+                gpu.set_option("max_paths", max_paths)
+                g = gpu.render(w, h, spp, 50, 77, flags)
+                H.assert_bits(g["sum"], osum, f"{w}x{h}@{spp} max_paths={max_paths}")
+                assert g["stats"].rays == ost.rays
+        finally:
+            gpu.set_option("max_paths", 1 << 30)
+
+
 def test_tiled_path_ids(gpu, orc):
     """With a BVH walk the persistent engine enumerates pixels in 8x8 tiles (option tile_paths, rt_kernels.h tile_pixel).
     That only changes which lane traces which path: the image must equal the row-order one and the oracle's, also when
