@@ -305,7 +305,9 @@ int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32
  * mapping and 4 the [-1,1] mapping of Randomizer.h:9-26 applied to the raw bits of x, 5 the raw shared-denominator
  * division sequence of the rect test (the hardware's f32 division with the denominator-only part hoisted; it equals
  * x/y bit for bit only inside its operand range and has NO fallback of its own -- the render kernel checks the range
- * per ray and takes plain divides outside it), 6 whether (x, y) lies inside that range (1.0) or not (0.0).
+ * per ray and takes plain divides outside it), 6 whether (x, y) lies inside that range (1.0) or not (0.0),
+ * 7 the render kernels' square root (the lean correctly rounded form when a whole wave's operands lie in [2^-60, 2^60],
+ * the general expansion otherwise), 8 the lean form alone (promised only inside that range).
  * y is required for ops 0, 5 and 6. */
 int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
 /* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: uv = n (u,v) pairs -> n RGB triples of texture `tex` */

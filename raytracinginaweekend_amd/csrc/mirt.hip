@@ -964,7 +964,7 @@ extern "C" int mirt_tex_sample_batch(mirt_ctx *c, uint32_t tex, const float *uv,
 
 extern "C" int mirt_arith_batch(mirt_ctx *c, uint32_t op, const float *x, const float *y, size_t n, float *out)
 {
-    if (!c || !x || !out || op > 6 || ((op == 0 || op >= 5) && !y)) return MIRT_ERR_ARG;
+    if (!c || !x || !out || op > 8 || ((op == 0 || op == 5 || op == 6) && !y)) return MIRT_ERR_ARG;
     if (!n) return MIRT_OK;
     CHECK_N(n);
     HIPCHK(c, hipSetDevice(c->device));

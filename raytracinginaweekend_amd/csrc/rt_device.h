@@ -22,7 +22,27 @@ namespace mirt {
 #ifndef MIRT_TEXP
 #define MIRT_TEXP 0
 #endif
-#define MIRT_SQRT(x) ((MIRT_TEXP & 2) ? __builtin_amdgcn_sqrtf(x) : __builtin_sqrtf(x))
+// The correctly rounded square root of an operand in [2^-60, 2^60]: the hardware's v_sqrt_f32 (within 1 ulp) and the choice
+// between its neighbours by the sign of the two residuals x - s*(s -+ 1ulp) -- the core of the compiler's own 17-instruction
+// expansion of sqrtf, without the seven instructions that rescale denormal operands and pass zero / infinity through.
+__device__ __forceinline__ float sqrt_in_range(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    s = r_dn <= 0.0f ? s_dn : s;
+    s = r_up > 0.0f ? s_up : s;
+    return s;
+}
+// sqrtf for a wave: the lean form when every active lane's operand is in its range (which the squared lengths and
+// discriminants of this path are, all but never), the compiler's general expansion for the whole wave otherwise.  Same bits.
+__device__ __forceinline__ float sqrt_wave(float x)
+{
+    const bool in_range = (x >= 0x1p-60f) & (x <= 0x1p60f);                 // false for zero, denormals, negatives, infinity and NaN
+    if (__builtin_amdgcn_ballot_w64(!in_range) == 0ull) return sqrt_in_range(x);
+    return __builtin_sqrtf(x);
+}
+#define MIRT_SQRT(x) ((MIRT_TEXP & 2) ? __builtin_amdgcn_sqrtf(x) : sqrt_wave(x))
 
 // ----------------------------------------------------------------------------- Vec3.h / Ray.h
 struct f3 { float x, y, z; };

@@ -1295,7 +1295,7 @@ __global__ void k_philox_batch(const uint32_t *ctr, uint32_t n, uint32_t k0, uin
 }
 
 // arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a),
-// 5 div_by(div_prepare(b), a), 6 whether (a, b) lies where 5 promises the bits of a / b
+// 5 div_by(div_prepare(b), a), 6 whether (a, b) lies where 5 promises the bits of a / b, 7 sqrt_wave(a), 8 sqrt_in_range(a)
 __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n, float *out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1308,7 +1308,9 @@ __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n,
     case 3: r = map_unorm(__float_as_uint(a)); break;
     case 4: r = map_pm1(__float_as_uint(a)); break;
     case 5: r = div_by(div_prepare(b), a); break;                        // the shared-denominator division of rect_run, raw
-    default: r = (div_den_ok(b) & div_num_ok(a)) ? 1.0f : 0.0f; break;     // 6: inside the operand range where 5 promises the bits of a / b
+    case 6: r = (div_den_ok(b) & div_num_ok(a)) ? 1.0f : 0.0f; break;       // inside the operand range where 5 promises the bits of a / b
+    case 7: r = sqrt_wave(a); break;                                      // the render kernels' square root (lean form per wave, rt_device.h)
+    default: r = sqrt_in_range(a); break;                                 // 8: the lean form alone, promised for [2^-60, 2^60]
     }
     out[i] = r;
 }

@@ -35,6 +35,26 @@ def test_arith_blocks(gpu, orc):
     H.assert_bits(gpu.arith_batch(4, raw.view(np.float32)), ((d / 4294967295.0) * 2.0 + -1.0).astype(np.float32), "map_pm1/all")
 
 
+def test_lean_square_root(gpu):
+    """sqrt_in_range / sqrt_wave (rt_device.h): the render kernels' square root must be the correctly rounded one.  Every
+    float of eight whole binades spread over [2^-60, 2^60] (2^26 operands: all mantissas, even and odd exponents, both ends
+    of the range), the range limits, and a mixed batch with zeros, denormals, infinities, negatives and NaN in the same
+    waves (the general path) -- against numpy's IEEE sqrt, bit for bit."""
+    mant = np.arange(1 << 23, dtype=np.uint32)
+    for e in (-60, -59, -31, -2, -1, 0, 1, 30, 59):
+        x = (np.uint32((127 + e) << 23) | mant).view(np.float32)
+        want = np.sqrt(x.astype(np.float64)).astype(np.float32)                  # double sqrt rounded to float = correctly rounded float sqrt
+        H.assert_bits(gpu.arith_batch(8, x), want, f"sqrt_in_range, binade 2^{e}")
+        H.assert_bits(gpu.arith_batch(7, x[::7]), want[::7], f"sqrt_wave, binade 2^{e}")
+    edge = np.array([2.0 ** -60, 2.0 ** 60, np.nextafter(np.float32(2.0 ** 60), np.float32(0))], np.float32)
+    H.assert_bits(gpu.arith_batch(8, edge), np.sqrt(edge.astype(np.float64)).astype(np.float32), "range limits")
+    rng = np.random.default_rng(3)
+    mix = (rng.normal(size=65536) * 10.0 ** rng.uniform(-44, 38, 65536)).astype(np.float32)
+    mix[::97] = 0.0; mix[5::101] = np.inf; mix[7::103] = np.nan; mix[11::89] = 1e-41; mix[13::83] = -0.0
+    with np.errstate(all="ignore"):
+        H.assert_bits(gpu.arith_batch(7, mix), np.sqrt(mix.astype(np.float64)).astype(np.float32), "sqrt_wave, mixed waves")
+
+
 def test_shared_denominator_division(gpu):
     """div_prepare/div_by (rt_device.h: the hardware division sequence with the denominator-only part hoisted) must
     give the bits of `/` wherever it promises them (|den| in [2^-20, 2^20], |x| in [2^-40, 2^40] or x == +0): 2^26
