@@ -300,7 +300,7 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
         float disc = b * b - 4 * a * c;
         bool in = false;
         if (disc > 0) {                                                  // one exit, flags instead of early returns
-            float sq = __builtin_sqrtf(disc);
+            float sq = MIRT_SQRT(disc);
             float t = (-b - sq) / (2.0f * a);
             in = (t <= t_max) & (t >= t_min);
             if (!in) { t = (-b + sq) / (2.0f * a); in = (t <= t_max) & (t >= t_min); }
