@@ -307,8 +307,9 @@ int mirt_philox_batch(mirt_ctx *ctx, const uint32_t *ctr, size_t n, const uint32
  * x/y bit for bit only inside its operand range and has NO fallback of its own -- the render kernel checks the range
  * per ray and takes plain divides outside it), 6 whether (x, y) lies inside that range (1.0) or not (0.0),
  * 7 the render kernels' square root (the lean correctly rounded form when a whole wave's operands lie in [2^-60, 2^60],
- * the general expansion otherwise), 8 the lean form alone (promised only inside that range).
- * y is required for ops 0, 5 and 6. */
+ * the general expansion otherwise), 8 the lean form alone (promised only inside that range), 9 the unsigned quotient
+ * bits(x) / bits(y) through the host-made reciprocal the render kernels split path ids with (result as bits).
+ * y is required for ops 0, 5, 6 and 9. */
 int mirt_arith_batch(mirt_ctx *ctx, uint32_t op, const float *x, const float *y, size_t n, float *out);
 /* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147: uv = n (u,v) pairs -> n RGB triples of texture `tex` */
 int mirt_tex_sample_batch(mirt_ctx *ctx, uint32_t tex, const float *uv, size_t n, float *rgb_out);

@@ -521,6 +521,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     // BVH walks gain ~2 % from compact 8x8 patches of camera rays; the list walk loses ~3 % (paths of one patch end together)
     a.tiles_x = (c->tile_paths && mode != 0 && p->width % 8u == 0 && p->height % 8u == 0) ? p->width / 8u : 0u;
+    a.by_width = fastdiv_make(a.width); a.by_tiles_x = fastdiv_make(a.tiles_x);
     uint32_t batch = 0;
     const bool timed = stats && c->time_launches;
     if (timed) while (c->ev_pool.size() < 2 * (size_t)n_batches) { hipEvent_t e; HIPCHK(c, hipEventCreate(&e)); c->ev_pool.push_back(e); }
@@ -530,7 +531,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
         for (uint32_t stile = 0; stile < n_s_tiles; ++stile, ++batch) {
             const uint32_t s0 = spp_begin + stile * S;
             const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
-            a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_paths = np * ns;
+            a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_paths = np * ns; a.by_npix = fastdiv_make(np);
             a.cursor = counts + batch * per_batch; a.hist = a.cursor + 1;
             // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim.  At most 512 ids: what a wave
             // still holds when the cursor runs dry is the tail of the launch (exits spread over 0.72 ms with 2048, 0.65 with 512)
@@ -682,6 +683,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     a.sc = mode == 2 ? c->sc2 : c->sc; a.cam = c->cam;
     if (bind_spill(c, a.sc, grid_max)) return fail(c, MIRT_ERR_NOMEM, "mirt_render_device: hipMalloc of the traversal-stack spill area failed"); a.rad = (RadSlot *)c->d_rad.p;
     a.width = p->width; a.height = p->height; a.max_depth = p->max_depth; a.flags = p->flags;
+    a.by_width = fastdiv_make(a.width);
     a.k0 = (uint32_t)p->seed; a.k1 = (uint32_t)(p->seed >> 32);
     a.chunk_shift = chunk_shift; a.cap_slots = (uint32_t)cap_slots; a.overflow = overflow;
     uint32_t launches = 0, batch = 0;
@@ -964,7 +966,7 @@ extern "C" int mirt_tex_sample_batch(mirt_ctx *c, uint32_t tex, const float *uv,
 
 extern "C" int mirt_arith_batch(mirt_ctx *c, uint32_t op, const float *x, const float *y, size_t n, float *out)
 {
-    if (!c || !x || !out || op > 8 || ((op == 0 || op == 5 || op == 6) && !y)) return MIRT_ERR_ARG;
+    if (!c || !x || !out || op > 9 || ((op == 0 || op == 5 || op == 6 || op == 9) && !y)) return MIRT_ERR_ARG;
     if (!n) return MIRT_OK;
     CHECK_N(n);
     HIPCHK(c, hipSetDevice(c->device));

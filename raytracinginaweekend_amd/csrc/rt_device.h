@@ -57,6 +57,31 @@ __device__ __forceinline__ f3 neg(f3 a) { return mk(0.0f - a.x, 0.0f - a.y, 0.0f
 __device__ __forceinline__ float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }      // Vec3.h:90-93
 __device__ __forceinline__ float get(f3 a, uint32_t i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 __device__ __forceinline__ void set(f3 &a, uint32_t i, float f) { if (i == 0) a.x = f; else if (i == 1) a.y = f; else a.z = f; }
+// ----------------------------------------------------------------------------- n / d for a divisor known before the launch
+// The image width and the pixels of a batch divide every path id (sample = id / npix, row = pixel / width); the compiler's
+// expansion of a 32-bit division by a run-time value is ~20 instructions.  With the divisor's 33-bit reciprocal made once on
+// the host (the round-up method of Granlund & Montgomery, "add" form valid for every 32-bit n) it is a multiply-high, a
+// subtract, two shifts and an add.  d == 1 is flagged (its reciprocal does not fit).
+struct FastDiv { uint32_t m, sh, one, d; };
+__host__ __device__ inline FastDiv fastdiv_make(uint32_t d)
+{
+    FastDiv f; f.d = d; f.one = d <= 1u ? 1u : 0u; f.m = 0u; f.sh = 0u;
+    if (d <= 1u) return f;
+    uint32_t l = 31u; while (!((d >> l) & 1u)) --l;                       // floor(log2 d)
+    if ((d & (d - 1u)) == 0u) { f.m = 0u; f.sh = l - 1u; return f; }      // power of two: ((n - 0) >> 1) >> (l - 1)
+    const unsigned long long two_l = 1ull << (32u + l);
+    unsigned long long m = two_l / d; const unsigned long long rem = two_l - m * d;
+    m = 2ull * m + ((2ull * rem >= d) ? 1ull : 0ull);                     // floor(2^(33+l) / d), low 32 bits kept below
+    f.m = (uint32_t)(m + 1ull); f.sh = l;
+    return f;
+}
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv &f)
+{
+    const uint32_t q = __umulhi(n, f.m);
+    const uint32_t t = ((n - q) >> 1) + q;
+    return f.one ? n : (t >> f.sh);                                      // f is wave-uniform: a scalar select
+}
+
 // ----------------------------------------------------------------------------- many IEEE quotients, one denominator
 // x / den for several x (the rects of one orientation all divide by the same ray-direction component).  This is the
 // hardware's own f32 division sequence (v_div_scale x2, v_rcp, 2 fma on the reciprocal, mul, 3 fma, v_div_fmas,

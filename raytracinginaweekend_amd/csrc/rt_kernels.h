@@ -95,6 +95,7 @@ struct BounceArgs {
     mirt_camera cam;
     uint32_t width, height, pix0, npix, spp0;
     uint32_t depth, max_depth, flags, k0, k1;
+    FastDiv by_width;              // pixel / width (rt_device.h fast_div)
 };
 
 // MIRT_EXP: ablation bits for timing experiments on the depth>=1 kernel (tools/ablate.sh); never set in the product
@@ -259,7 +260,7 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         // when four_a * c was absorbed (disc == bb) the sphere is parked and judged by its roots as written.
         const bool behind = (b > 0.0f) & (c > 0.0f) & (disc < bb);
         const bool cross = (disc > 0) & !behind;
-        if (__ballot(cross & (p_idx >= 0)) != 0ull) resolve();
+        if (!(MIRT_TEXP & 32) && __ballot(cross & (p_idx >= 0)) != 0ull) resolve();   // TEXP 32 (timing only): a second crossing overwrites the parked sphere
         if (cross) { p_b = b; p_disc = disc; p_idx = (int32_t)q1.w; }
     }
     resolve();
@@ -499,13 +500,20 @@ __device__ __forceinline__ uint32_t tile_pixel(uint32_t g, uint32_t tiles_x, uin
     const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
     return (ty * 8u + (in >> 3)) * width + tx * 8u + (in & 7u);
 }
+__device__ __forceinline__ uint32_t tile_pixel(uint32_t g, const FastDiv &by_tiles_x, uint32_t width)   // by_tiles_x.d == tiles_x
+{
+    if (by_tiles_x.d == 0u) return g;
+    const uint32_t tile = g >> 6, in = g & 63u;
+    const uint32_t ty = fast_div(tile, by_tiles_x), tx = tile - ty * by_tiles_x.d;
+    return (ty * 8u + (in >> 3)) * width + tx * 8u + (in & 7u);
+}
 
 // ---------------------------------------------------------------------------------- ray generation
 // HomemadeRayTracer.cpp:114-131 + SimpleCamera.cpp:55-60 + Randomizer.h:50-58
 template <class Args>
 __device__ __forceinline__ void generate_ray(const Args &a, uint32_t pixel, uint32_t sample, f3 &o, f3 &d)
 {
-    uint32_t i = pixel % a.width, j = pixel / a.width;
+    const uint32_t j = fast_div(pixel, a.by_width), i = pixel - j * a.width;
     PhiloxKeyed g; g.pixel = pixel; g.sample = sample; g.stage = 0; g.k0 = a.k0; g.k1 = a.k1;
     uint32_t r[4]; g.block(0, r);
     float u, v;
@@ -784,6 +792,7 @@ struct TraceArgs {
     uint32_t width, height, pix0, npix, spp0;
     uint32_t max_depth, flags, k0, k1;
     uint32_t tiles_x;              // > 0: path ids run over 8x8 pixel tiles (tile_pixel), tiles_x = width / 8
+    FastDiv by_npix, by_width, by_tiles_x;   // reciprocals of the three divisors of a path id (rt_device.h fast_div), made by the host
     uint32_t slice_want;           // ACCEL 3: finished walks that end a slice (bvh2_slice)
     uint32_t leaf_want;            // ACCEL 2, 3: lanes waiting on a leaf that start an object-test pass (closest_bvh2)
     // second stream (MIRT_DEFER_MD, list walk): per-wave queues in HBM, plane-major.  mdq: MDQ_PLANES float4 planes of MDQ_CAP
@@ -873,6 +882,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
         return true;
     };
+    // the pixel of a path id's pixel index: the list walk never tiles its path ids (mirt.hip sets tiles_x = 0 for it); the BVH
+    // walks divide by the plain argument here (its reciprocal, three more SGPRs live across their loop, measured 2 % slower)
+    auto path_pixel = [&](uint32_t g) -> uint32_t { if constexpr (ACCEL == 0) return g; else return tile_pixel(g, a.tiles_x, a.width); };
     bool exhausted = false;
     // the lane's path
     bool live = false;
@@ -940,7 +952,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     o = mk(q0.x, q0.y, q0.z); d = mk(q0.w, q1.x, q1.y); thr = mk(q1.z, q1.w, q2.x);
                     pid = __float_as_uint(q2.y); depth = __float_as_uint(q2.z);
                     const uint32_t sl = __float_as_uint(q2.w);
-                    sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
+                    sample = a.spp0 + sl; pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
                     live = true;
                 }
                 r_cnt -= take;
@@ -955,9 +967,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     if (lane < g) {
                         const TraceArgs &ka = late_args();
                         const uint32_t id = w_next + lane;
-                        const uint32_t sl = id / ka.npix, pl = id - sl * ka.npix;
+                        const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
                         f3 go, gd;
-                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.tiles_x, ka.width), ka.spp0 + sl, go, gd);
+                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width), ka.spp0 + sl, go, gd);
                         const uint32_t e = cnt + lane;
                         stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
@@ -975,7 +987,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     const float4 qa = stash.a[e], qb = stash.b[e];
                     o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                     const uint32_t sl = __float_as_uint(qb.w);
-                    sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
+                    sample = a.spp0 + sl; pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
                     thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                 }
                 const uint32_t n_idle = (uint32_t)__popcll(idle);
@@ -997,7 +1009,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const float4 qa = stash.a[e], qb = stash.b[e];
                         o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                         const uint32_t sl = __float_as_uint(qb.w);
-                        sample = a.spp0 + sl; pixel = tile_pixel(a.pix0 + (pid - sl * a.npix), a.tiles_x, a.width);
+                        sample = a.spp0 + sl; pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
                         thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                     }
                     cnt -= take; served += take;
@@ -1008,9 +1020,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     if (lane < g) {
                         const TraceArgs &ka = late_args();
                         const uint32_t id = w_next + lane;
-                        const uint32_t sl = id / ka.npix, pl = id - sl * ka.npix;
+                        const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
                         f3 go, gd;
-                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.tiles_x, ka.width), ka.spp0 + sl, go, gd);
+                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width), ka.spp0 + sl, go, gd);
                         stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
                     }
@@ -1295,7 +1307,8 @@ __global__ void k_philox_batch(const uint32_t *ctr, uint32_t n, uint32_t k0, uin
 }
 
 // arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a),
-// 5 div_by(div_prepare(b), a), 6 whether (a, b) lies where 5 promises the bits of a / b, 7 sqrt_wave(a), 8 sqrt_in_range(a)
+// 5 div_by(div_prepare(b), a), 6 whether (a, b) lies where 5 promises the bits of a / b, 7 sqrt_wave(a), 8 sqrt_in_range(a),
+// 9 fast_div(bits a, fastdiv_make(bits b)) as bits
 __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n, float *out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1310,6 +1323,7 @@ __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n,
     case 5: r = div_by(div_prepare(b), a); break;                        // the shared-denominator division of rect_run, raw
     case 6: r = (div_den_ok(b) & div_num_ok(a)) ? 1.0f : 0.0f; break;       // inside the operand range where 5 promises the bits of a / b
     case 7: r = sqrt_wave(a); break;                                      // the render kernels' square root (lean form per wave, rt_device.h)
+    case 9: r = __uint_as_float(fast_div(__float_as_uint(a), fastdiv_make(__float_as_uint(b)))); break;   // path id / (pixels of a batch, image width)
     default: r = sqrt_in_range(a); break;                                 // 8: the lean form alone, promised for [2^-60, 2^60]
     }
     out[i] = r;

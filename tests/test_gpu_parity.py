@@ -55,6 +55,24 @@ def test_lean_square_root(gpu):
         H.assert_bits(gpu.arith_batch(7, mix), np.sqrt(mix.astype(np.float64)).astype(np.float32), "sqrt_wave, mixed waves")
 
 
+def test_reciprocal_integer_division(gpu):
+    """fast_div (rt_device.h): path id / pixels-of-a-batch and pixel / width through a host-made 33-bit reciprocal must be the
+    integer quotient for every 32-bit numerator: all divisors up to 4100 and a spread of large ones (powers of two, their
+    neighbours, primes, 2^32 - 1) against numerators at both ends of the range, around every multiple boundary, and random."""
+    rng = np.random.default_rng(11)
+    divs = np.concatenate([np.arange(1, 4101, dtype=np.uint64), 2 ** np.arange(12, 32, dtype=np.uint64), 2 ** np.arange(12, 32, dtype=np.uint64) - 1,
+                           2 ** np.arange(12, 32, dtype=np.uint64) + 1, np.array([1048573, 2073600, 16777259, 2 ** 31 + 11, 2 ** 32 - 2, 2 ** 32 - 1], np.uint64),
+                           rng.integers(4100, 2 ** 32, 3000, dtype=np.uint64)])
+    for chunk in np.array_split(divs, 8):
+        k = rng.integers(0, 2 ** 32, (chunk.size, 24), dtype=np.uint64) // chunk[:, None]         # multiples k*d near which the quotient steps
+        near = (k * chunk[:, None])[:, :, None] + np.array([-1, 0, 1], np.int64)[None, None, :].astype(np.uint64)
+        n = np.concatenate([near.reshape(chunk.size, -1) & np.uint64(0xFFFFFFFF), rng.integers(0, 2 ** 32, (chunk.size, 52), dtype=np.uint64),
+                            np.tile(np.array([0, 1, 2, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 2, 2 ** 32 - 1], np.uint64), (chunk.size, 1))], axis=1)
+        d = np.repeat(chunk[:, None], n.shape[1], axis=1)
+        got = gpu.arith_batch(9, n.astype(np.uint32).ravel().view(np.float32), d.astype(np.uint32).ravel().view(np.float32)).view(np.uint32)
+        assert np.array_equal(got, (n // d).astype(np.uint32).ravel())
+
+
 def test_shared_denominator_division(gpu):
     """div_prepare/div_by (rt_device.h: the hardware division sequence with the denominator-only part hoisted) must
     give the bits of `/` wherever it promises them (|den| in [2^-20, 2^20], |x| in [2^-40, 2^40] or x == +0): 2^26
