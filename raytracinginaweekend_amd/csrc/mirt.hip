@@ -74,6 +74,7 @@ struct mirt_ctx {
     bool time_launches = false;
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene
+    uint32_t paths_per_lane = 1;            // list walk: 1 = k_trace; 2 = k_trace2 (two paths in every lane share the passes few lanes need: measured 6 % slower, kept under test)
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
     uint32_t leaf_wait = MIRT_LEAF_WANT;   // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2)
@@ -195,6 +196,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "leaf_wait")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "leaf_wait out of range"); c->leaf_wait = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "walk_yield")) { if (value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "walk_yield out of range"); c->walk_yield = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
+    if (!strcmp(name, "paths_per_lane")) { if (value != 1 && value != 2) return fail(c, MIRT_ERR_ARG, "paths_per_lane is 1 or 2"); c->paths_per_lane = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "blocks_per_cu")) { if (value < 0 || value > 65536) return fail(c, MIRT_ERR_ARG, "blocks_per_cu out of range"); c->blocks_per_cu = (uint32_t)value; return MIRT_OK; }
     return fail(c, MIRT_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -431,11 +433,14 @@ static uint32_t trace_lds(const mirt_ctx *c, int mode)
 {
     return mode >= 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
 }
+// The list walk of a scene without image textures runs two paths per lane (k_trace2) when the paths_per_lane option says 2
+static bool two_paths(const mirt_ctx *c, int mode) { return mode == 0 && c->sc.n_textures == 0 && c->paths_per_lane == 2 && !MIRT_DEFER_MD; }
 static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
 {
     const uint32_t lds = trace_lds(c, mode);
     const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     dim3 g(grid), b(MIRT_BLOCK);
+    if (two_paths(c, mode)) { if (pl) hipLaunchKernelGGL((k_trace2<true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace2<false>), g, b, lds, st, a); return; }
 #define MIRT_CALL(A, P, T) do { if (A == 0) hipLaunchKernelGGL((k_trace<P, T>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace_bvh<(A == 0 ? 1 : A), P, T>), g, b, lds, st, a); } while (0)
     MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
 #undef MIRT_CALL
@@ -446,6 +451,11 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
     const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
     int n = 0;
     hipError_t e = hipSuccess;
+    if (two_paths(c, mode)) {
+        e = pl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace2<true>, MIRT_BLOCK, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace2<false>, MIRT_BLOCK, lds);
+        if (e != hipSuccess || n < 1) { (void)hipGetLastError(); return 5; }
+        return (uint32_t)n;
+    }
 #define MIRT_CALL(A, P, T) do { if (A == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace<P, T>, MIRT_BLOCK, lds); else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_trace_bvh<(A == 0 ? 1 : A), P, T>, MIRT_BLOCK, lds); } while (0)
     MIRT_TRACE_DISPATCH(mode, pl, tex, MIRT_CALL);
 #undef MIRT_CALL

@@ -1139,6 +1139,381 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------- two paths per lane (list walk)
+// k_trace2 (option paths_per_lane = 2; measured, NOT the default): the persistent kernel with TWO paths in every lane.  A wave
+// pass costs its instructions whether 9 or 64 lanes need them, and the metal/dielectric half of Scatter is ~160 instructions
+// for ~9 lanes.  With two independent paths per lane that pass serves 128 paths: a lane shades whichever of its two paths
+// needs it (a lane whose two paths both do keeps the second for the next iteration, where it meets the same vertex and the
+// same keyed draws again); the pending draws of both paths share their cooperative rounds, in-loop sphere roots share a pass,
+// and every scene record fetched by the list walk is tested against two rays.  Per-path arithmetic, Philox keys and the
+// radiance slot are those of k_trace: the images are bit-identical (test_two_paths_per_lane_is_bit_identical).
+// Measured on Cornell 1024^2@512 (profiles/r02_two_paths.txt): lane use 68.2 -> 72.6 %, but 887 VALU instructions per 64
+// rays against 885 -- the selects that route two paths through one pass, the second owner's side of every cooperative round
+// and the extra root passes cost what the shared pass saves -- and 95 VGPRs leave 5 waves per SIMD instead of 7, which issue
+// 4 % fewer instructions per second: 58.0 ms against 54.7.  4 waves measure the same, 6 (80 VGPRs, spills) 66 ms.
+#ifndef MIRT_POOL_DRAWS
+#define MIRT_POOL_DRAWS 1
+#endif
+#ifndef MIRT_LIST2_WAVES
+#define MIRT_LIST2_WAVES 5
+#endif
+template <int A, int B, int C, bool FAST>
+__device__ __forceinline__ void rect_loop2(ListPtr &q, uint32_t &p, uint32_t end, const f3 (&o)[2], const f3 (&d)[2],
+                                           float t_min, float (&t_max)[2], int32_t (&best)[2])
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    if (p >= end) return;
+    float dc[2], da[2], db[2]; DivBy by_dc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        dc[k] = C == 0 ? d[k].x : (C == 1 ? d[k].y : d[k].z);
+        da[k] = A == 0 ? d[k].x : (A == 1 ? d[k].y : d[k].z); db[k] = B == 0 ? d[k].x : (B == 1 ? d[k].y : d[k].z);
+        by_dc[k] = div_prepare(dc[k]);
+    }
+    for (; p < end; ++p, q += 4) {
+        const u32x4 q0 = q[0], q1 = q[1];
+        const u32x2 q2 = *(const __attribute__((address_space(4))) u32x2 *)(q + 2);
+        const int32_t idx = (int32_t)q1.w;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                       // rect_loop's body, once per path
+            const f3 ol = o[k] - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            const float oc = C == 0 ? ol.x : (C == 1 ? ol.y : ol.z);
+            const float oa = A == 0 ? ol.x : (A == 1 ? ol.y : ol.z), ob = B == 0 ? ol.x : (B == 1 ? ol.y : ol.z);
+            const float num = __uint_as_float(q2.y) - oc;
+            const float t = FAST ? div_by(by_dc[k], num) : num / dc[k];     // Hitables.cpp:95
+            const float a = oa + t * da[k];
+            const float b = ob + t * db[k];
+            const bool in_t = (t >= t_min) & ((t < t_max[k]) | ((t == t_max[k]) & (idx > best[k])));
+            const bool in_ab = (a >= __uint_as_float(q1.x)) & (a <= __uint_as_float(q1.y)) & (b >= __uint_as_float(q1.z)) & (b <= __uint_as_float(q2.x));
+            const bool hit = in_t & in_ab;
+            t_max[k] = hit ? t : t_max[k];
+            best[k] = hit ? idx : best[k];
+        }
+    }
+}
+// closest_list for the two rays of a lane: the same tests in the same order per ray, one record fetch for both
+template <bool PLDS>
+__device__ __forceinline__ void closest_list2(const SceneDev &sc, const LdsView &v, const f3 (&o)[2], const f3 (&d)[2],
+                                              float t_min, float (&t_max)[2], int32_t (&best)[2])
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    best[0] = -1; best[1] = -1;
+    uint32_t p = 0;
+    ListPtr q = (ListPtr)sc.lprims;
+    if (sc.lend[2] != 0u) {
+        bool fast = (sc.list_fast != 0u) & (t_min >= 0x1p-19f);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                        // closest_list's range test, both rays
+            const float d_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[k].x), __builtin_fabsf(d[k].y)), __builtin_fabsf(d[k].z));
+            const float d_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d[k].x), __builtin_fabsf(d[k].y)), __builtin_fabsf(d[k].z));
+            const float o_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o[k].x), __builtin_fabsf(o[k].y)), __builtin_fabsf(o[k].z));
+            fast = fast & (d_hi <= 0x1p20f) & (d_lo >= 0x1p-20f) & (o_hi <= 0x1p38f);
+        }
+        if (__ballot(!fast) == 0ull) {
+            rect_loop2<0, 1, 2, true>(q, p, sc.lend[0], o, d, t_min, t_max, best);
+            rect_loop2<0, 2, 1, true>(q, p, sc.lend[1], o, d, t_min, t_max, best);
+            rect_loop2<2, 1, 0, true>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+        } else {
+            rect_loop2<0, 1, 2, false>(q, p, sc.lend[0], o, d, t_min, t_max, best);
+            rect_loop2<0, 2, 1, false>(q, p, sc.lend[1], o, d, t_min, t_max, best);
+            rect_loop2<2, 1, 0, false>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+        }
+    }
+    float two_a[2], four_a[2], inv2a[2], p_b[2] = { 0.0f, 0.0f }, p_disc[2] = { 0.0f, 0.0f }; int32_t p_idx[2] = { -1, -1 };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float a_dd = dot(d[k], d[k]);                                  // Hitables.cpp:22,26,31 (unrotated spheres)
+        two_a[k] = 2.0f * a_dd; four_a[k] = 4 * a_dd; inv2a[k] = __builtin_amdgcn_rcpf(two_a[k]);
+    }
+    const float t_lo = t_min * 0.99999f, t_hi = t_min * 1.00001f;
+    // The roots of parked spheres, one pass for both paths: a lane resolves the parked sphere of path 0 if `w0`, else that of
+    // path 1 if `w1` (closest_list's `resolve`, operands selected).  Lanes that want both are served by a second pass.
+    auto resolve_pass = [&](bool w0, bool w1) {
+        const bool s1 = !w0;
+        if (w0 | w1) {
+            const float pb = s1 ? p_b[1] : p_b[0], pd = s1 ? p_disc[1] : p_disc[0], ta = s1 ? two_a[1] : two_a[0], ia = s1 ? inv2a[1] : inv2a[0];
+            const float tm = s1 ? t_max[1] : t_max[0];
+            const int32_t pi = s1 ? p_idx[1] : p_idx[0], bs = s1 ? best[1] : best[0];
+            const float sq = MIRT_SQRT(pd);
+            const float n1 = -pb - sq, n2 = -pb + sq;
+            const float q1 = n1 * ia;
+            const bool first = q1 > t_hi, second = q1 < t_lo;
+            float t = (first ? n1 : n2) / ta;
+            if (!(first | second)) {
+                t = n1 / ta;                                                 // Hitables.cpp:31
+                if (!(t >= t_min)) t = n2 / ta;                              // :41
+            }
+            const bool acc = (t >= t_min) & ((t < tm) | ((t == tm) & (pi > bs)));
+            t_max[0] = (acc & !s1) ? t : t_max[0]; best[0] = (acc & !s1) ? pi : best[0]; p_idx[0] = s1 ? p_idx[0] : -1;
+            t_max[1] = (acc & s1) ? t : t_max[1];  best[1] = (acc & s1) ? pi : best[1];  p_idx[1] = s1 ? -1 : p_idx[1];
+        }
+    };
+    for (; p < sc.lend[3]; ++p, q += 4) {
+        const u32x4 q0 = q[0], q1 = q[1];
+        bool cross[2]; float nb[2], nd[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const f3 oc = o[k] - mk(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z));
+            const float b = 2.0f * dot(d[k], oc);
+            const float c = dot(oc, oc) - __uint_as_float(q1.z);
+            const float bb = b * b;
+            const float disc = bb - four_a[k] * c;
+            const bool behind = (b > 0.0f) & (c > 0.0f) & (disc < bb);       // see closest_list
+            cross[k] = (disc > 0) & !behind;
+            nb[k] = b; nd[k] = disc;
+        }
+        bool w0 = cross[0] & (p_idx[0] >= 0), w1 = cross[1] & (p_idx[1] >= 0);
+        while (__ballot(w0 | w1) != 0ull) { resolve_pass(w0, w1); w1 = w0 & w1; w0 = false; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) if (cross[k]) { p_b[k] = nb[k]; p_disc[k] = nd[k]; p_idx[k] = (int32_t)q1.w; }
+    }
+    if (__ballot(p_idx[0] >= 0) != 0ull) resolve_pass(p_idx[0] >= 0, false);      // the end of the list: each path by itself (a lane with
+    if (__ballot(p_idx[1] >= 0) != 0ull) resolve_pass(false, p_idx[1] >= 0);      // a sphere parked on both would force two passes anyway)
+    for (; p < sc.n_prims; ++p, q += 4) {
+        const u32x4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        PrimRec pr;
+        pr.off[0] = __uint_as_float(q0.x); pr.off[1] = __uint_as_float(q0.y); pr.off[2] = __uint_as_float(q0.z); pr.info = q0.w;
+        pr.ga[0] = __uint_as_float(q1.x); pr.ga[1] = __uint_as_float(q1.y); pr.ga[2] = __uint_as_float(q1.z); pr.mat = q1.w;
+        pr.gb[0] = __uint_as_float(q2.x); pr.gb[1] = __uint_as_float(q2.y); pr.rot[0] = __uint_as_float(q2.z); pr.rot[1] = __uint_as_float(q2.w);
+        pr.rot[2] = __uint_as_float(q3.x); pr.rot[3] = __uint_as_float(q3.y); pr.rot[4] = __uint_as_float(q3.z); pr.rot[5] = __uint_as_float(q3.w);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float t;
+            if (prim_t(pr, o[k], d[k], t_min, t_max[k], t) && (t < t_max[k] || (int32_t)pr.mat > best[k])) { t_max[k] = t; best[k] = (int32_t)pr.mat; }
+        }
+    }
+}
+
+// coop_draws for the two paths of a lane: round 0 per path, then the pending draws of BOTH paths share the cooperative rounds
+// (up to 128 keys in LDS; a round serves the first 64 / G of them, the others wait their turn).  The owner of a key still takes
+// its first accepted iteration, so every path gets the very candidate its own loop would have stopped at.
+struct CoopLds2 { uint32_t pix[128], smp[128], it[128], stg[128]; };
+__device__ __forceinline__ void coop_draws2(CoopLds2 &cl, uint32_t lane, const uint32_t (&need)[2], const uint32_t (&pixel)[2], const uint32_t (&sample)[2],
+                                            const uint32_t (&stage)[2], uint32_t k0, uint32_t k1, f3 (&sphere_pt)[2], float (&unorm)[2])
+{
+    bool pending[2] = { false, false };
+    uint32_t next_it[2] = { 1u, 1u };
+    uint32_t w[2][3] = { { 0u, 0u, 0u }, { 0u, 0u, 0u } };         // the accepted candidates' raw words
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (need[k] != NEED_NONE) {                                 // round 0: block 0 serves all three materials
+            uint32_t r[4];
+            philox4x32_10(pixel[k], sample[k], stage[k], 0, k0, k1, r);
+            unorm[k] = map_unorm(r[0]);
+            w[k][0] = r[0]; w[k][1] = r[1]; w[k][2] = r[2];
+            pending[k] = (need[k] == NEED_SPHERE) & !candidate_inside(r);
+        }
+    }
+    for (;;) {
+        const unsigned long long m0 = __ballot(pending[0]), m1 = __ballot(pending[1]);
+        if ((m0 | m1) == 0ull) break;
+        const uint32_t n0 = (uint32_t)__popcll(m0), n = n0 + (uint32_t)__popcll(m1);
+        const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per served key
+        const uint32_t G = 1u << lg, n_served = n < (64u >> lg) ? n : (64u >> lg);
+        const uint32_t rank[2] = { rank_in(m0), n0 + rank_in(m1) };
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (pending[k]) { cl.pix[rank[k]] = pixel[k]; cl.smp[rank[k]] = sample[k]; cl.it[rank[k]] = next_it[k]; cl.stg[rank[k]] = stage[k]; }
+        wave_lds_sync();
+        const uint32_t e = lane >> lg, sub = lane & (G - 1u);
+        uint32_t r[4] = { 0u, 0u, 0u, 0u };
+        bool acc = false;
+        const uint32_t it = cl.it[e] + sub;                       // e < 64; entries >= n are stale and unused
+        if ((e < n_served) & (it < MIRT_REJECT_CAP)) {
+            philox4x32_10(cl.pix[e], cl.smp[e], cl.stg[e], it, k0, k1, r);
+            acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
+        }
+        const unsigned long long am = __ballot(acc);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool served = pending[k] & (rank[k] < n_served);
+            const uint32_t sh = served ? (rank[k] << lg) : 0u;                        // < 64 for a served key
+            const uint32_t bits = (uint32_t)(am >> sh) & ((1u << G) - 1u);            // its G helpers, lowest = earliest iteration
+            const bool got = served & (bits != 0u);
+            const int src4 = (int)((got ? sh + (uint32_t)__builtin_ctz(bits) : lane) << 2);
+            next_it[k] += (served & !got) ? G : 0u;
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[0]), c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[1]),
+                           c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[2]);
+            w[k][0] = got ? c0 : w[k][0]; w[k][1] = got ? c1 : w[k][1]; w[k][2] = got ? c2 : w[k][2];
+            pending[k] = pending[k] & !got;
+        }
+        __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (need[k] == NEED_SPHERE) sphere_pt[k] = mk(map_pm1(w[k][0]), map_pm1(w[k][1]), map_pm1(w[k][2]));
+}
+
+template <bool PLDS>
+__device__ __forceinline__ void trace_body2(const TraceArgs &a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ CoopLds2 s_coop[MIRT_BLOCK / 64];
+    constexpr uint32_t STASH_N = 128u;
+    __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
+    __shared__ uint32_t s_hist[65];
+
+    if (a.own_chunks == 0u && (uint64_t)blockIdx.x * a.claim >= a.n_paths) return;   // more workgroups than claims (uniform)
+    const LdsView lv = lds_view(a.sc, smem);
+    if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
+    lds_stage(a.sc, lv);                                            // ends with a barrier
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    auto &stash = s_stash[wave];
+
+    uint32_t cnt = 0, w_next = 0, w_end = 0, own_k = 0;            // wave-uniform bookkeeping, as in trace_body
+    auto next_range = [&]() -> bool {
+        if (own_k < a.own_chunks) {
+            w_next = (own_k * a.grid_waves + (blockIdx.x * (MIRT_BLOCK / 64) + wave)) * 64u; w_end = w_next + 64u;
+            ++own_k;
+            return true;
+        }
+        uint32_t b = 0;
+        if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
+        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+        if (b >= a.n_paths) return false;
+        w_next = b; w_end = (a.n_paths - b < a.claim) ? a.n_paths : b + a.claim;
+        return true;
+    };
+    bool exhausted = false;
+    // the lane's two paths.  A path slot that is not live still goes through the list walk (its tests cost nothing extra in a
+    // wave pass); it keeps a harmless finite ray and takes part in nothing else.
+    bool live[2] = { false, false };
+    f3 o[2] = { mk(0, 0, 0), mk(0, 0, 0) }, d[2] = { mk(1, 1, 1), mk(1, 1, 1) }, thr[2] = { mk(1.0f, 1.0f, 1.0f), mk(1.0f, 1.0f, 1.0f) };
+    uint32_t pid[2] = { 0, 0 }, pixel[2] = { 0, 0 }, sample[2] = { 0, 0 }, depth[2] = { 0, 0 };
+
+    for (;;) {
+        // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
+        if (cnt + 64u <= STASH_N && !exhausted) {
+            if (w_next == w_end && !next_range()) exhausted = true;
+            if (!exhausted) {
+                const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
+                if (lane < g) {
+                    const TraceArgs &ka = late_args();
+                    const uint32_t id = w_next + lane;
+                    const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
+                    f3 go, gd;
+                    generate_ray(ka, ka.pix0 + pl, ka.spp0 + sl, go, gd);       // the list walk never tiles its path ids
+                    const uint32_t e = cnt + lane;
+                    stash.a[e] = make_float4(go.x, go.y, go.z, gd.x);
+                    stash.b[e] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
+                }
+                w_next += g; cnt += g;
+                wave_lds_sync();
+            }
+        }
+        // ---- idle path slots take a fresh path from the top of the stash (slots of path 0 first)
+        const unsigned long long idle0 = __ballot(!live[0]), idle1 = __ballot(!live[1]);
+        if ((idle0 | idle1) != 0ull && cnt != 0u) {
+            const uint32_t n_i0 = (uint32_t)__popcll(idle0), n_idle = n_i0 + (uint32_t)__popcll(idle1);
+            const uint32_t rank[2] = { rank_in(idle0), n_i0 + rank_in(idle1) };
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!live[k] && rank[k] < cnt) {
+                    const uint32_t e = cnt - 1u - rank[k];
+                    const float4 qa = stash.a[e], qb = stash.b[e];
+                    o[k] = mk(qa.x, qa.y, qa.z); d[k] = mk(qa.w, qb.x, qb.y); pid[k] = __float_as_uint(qb.z);
+                    const uint32_t sl = __float_as_uint(qb.w);
+                    sample[k] = a.spp0 + sl; pixel[k] = a.pix0 + (pid[k] - sl * a.npix);
+                    thr[k] = mk(1.0f, 1.0f, 1.0f); depth[k] = 0; live[k] = true;
+                }
+            }
+            cnt -= (n_idle < cnt) ? n_idle : cnt;
+            wave_lds_sync();                                        // the freed entries are rewritten by the next top-up
+        }
+        if (__ballot(live[0] | live[1]) == 0ull) break;             // pool exhausted, stash empty, every path ended
+
+        // ---- phase 1: extend both paths (HomemadeRayTracer.cpp:160-162), classify each vertex
+        float t_max[2] = { 3.402823466e+38f, 3.402823466e+38f };   // FLT_MAX
+        int32_t best[2];
+        closest_list2<PLDS>(a.sc, lv, o, d, 0.001f, t_max, best);
+        bool done[2] = { false, false };
+        uint32_t need[2] = { NEED_NONE, NEED_NONE }, stage[2];
+        f3 hp[2], hn[2];                       // the hit's position and normal; hp is the path's radiance where `done`
+        uint32_t mi[2] = { 0u, 0u }, kind[2] = { 0u, 0u };   // material index and kind (a pointer kept across the draws would be a generic one: flat loads)
+        auto mat_of = [&](uint32_t i) -> const MatRec * {
+            if constexpr (PLDS) return (const MatRec *)((const unsigned char *)lv.mats + __umul24(i, (uint32_t)sizeof(MatRec)));
+            else return (i < a.sc.lds_mats) ? (const MatRec *)(lv.mats + i) : (a.sc.mats + i);
+        };
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            stage[k] = 1u + depth[k];
+            hp[k] = o[k]; hn[k] = d[k];
+            if (live[k]) {
+                if (best[k] < 0) {                                                     // :186
+                    hp[k] = thr[k] * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done[k] = true;
+                } else {
+                    const PrimRec *P = PLDS ? lv.prims : a.sc.prims;
+                    Hit h;
+                    prim_record(P[best[k]], best[k], o[k], d[k], t_max[k], false, h);
+                    if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
+                        hp[k] = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done[k] = true;
+                    } else if (!(depth[k] < a.max_depth)) {                            // :173-174
+                        hp[k] = mk(0.0f, 0.0f, 0.0f); done[k] = true;
+                    } else {
+                        hp[k] = h.pos; hn[k] = h.nrm;
+                        mi[k] = (uint32_t)h.mat; kind[k] = mat_of(mi[k])->kind;
+                        need[k] = scatter_need(kind[k], d[k], h.nrm, true);
+                    }
+                }
+            }
+        }
+        // ---- phase 2 (whole wave): the draws of Scatter for both paths, keyed by each path's own depth
+        f3 sp[2] = { mk(0.0f, 0.0f, 0.0f), mk(0.0f, 0.0f, 0.0f) }; float un[2] = { 0.0f, 0.0f };
+#if MIRT_POOL_DRAWS
+        coop_draws2(s_coop[wave], lane, need, pixel, sample, stage, a.k0, a.k1, sp, un);
+#else
+        coop_draws<true>(*(CoopLds *)&s_coop[wave], lane, need[0], pixel[0], sample[0], stage[0], a.k0, a.k1, sp[0], un[0]);
+        coop_draws<true>(*(CoopLds *)&s_coop[wave], lane, need[1], pixel[1], sample[1], stage[1], a.k0, a.k1, sp[1], un[1]);
+#endif
+        // ---- phase 3: the rest of Scatter.  Lambertian and light per path; metal and dielectric of both paths in one pass
+        bool md[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool shade = live[k] && !done[k];
+            md[k] = shade && ((kind[k] & 2u) != 0u);                                 // MIRT_MAT_METAL = 2, MIRT_MAT_DIELECTRIC = 3
+            if (shade && !md[k]) {
+                Scat s;
+                const MatRec *Mk = mat_of(mi[k]);
+                scatter_finish<false, 1>(*Mk, mk(Mk->albedo[0], Mk->albedo[1], Mk->albedo[2]), d[k], hp[k], hn[k], sp[k], un[k], s);
+                if (s.alive) { o[k] = hp[k]; d[k] = s.dir; thr[k] = thr[k] * s.atten; }
+                else { hp[k] = s.emits ? thr[k] * s.emitted : scale(thr[k], 0.0f); done[k] = true; }   // an absorbed path: thr * (0,0,0), :173
+            }
+        }
+        const bool retry1 = md[0] & md[1];                           // both paths of the lane: path 1 meets its vertex again next time
+        if (md[0] | md[1]) {
+            const bool s1 = !md[0];
+            const MatRec *SM = mat_of(s1 ? mi[1] : mi[0]);
+            const f3 din = s1 ? d[1] : d[0], pos = s1 ? hp[1] : hp[0], nrm = s1 ? hn[1] : hn[0], spt = s1 ? sp[1] : sp[0];
+            const float su = s1 ? un[1] : un[0];
+            Scat s;
+            scatter_finish<false, 2>(*SM, mk(SM->albedo[0], SM->albedo[1], SM->albedo[2]), din, pos, nrm, spt, su, s);
+            if (s1) {
+                if (s.alive) { o[1] = pos; d[1] = s.dir; thr[1] = thr[1] * s.atten; }
+                else { hp[1] = scale(thr[1], 0.0f); done[1] = true; }
+            } else {
+                if (s.alive) { o[0] = pos; d[0] = s.dir; thr[0] = thr[0] * s.atten; }
+                else { hp[0] = scale(thr[0], 0.0f); done[0] = true; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool rt = k == 1 && retry1;
+            if (live[k] && done[k]) {
+                store_rad(a.rad, pid[k], hp[k]);
+                atomicAdd(&s_hist[depth[k] < 63u ? depth[k] : 63u], 1u);
+                if (depth[k] > 63u) atomicAdd(&s_hist[64], depth[k] - 63u);
+                live[k] = false;
+            }
+            if (!rt) ++depth[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 65 && s_hist[threadIdx.x]) atomicAdd(a.hist + threadIdx.x, s_hist[threadIdx.x]);
+}
+template <bool PLDS>
+__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST2_WAVES) k_trace2(TraceArgs a) { trace_body2<PLDS>(a); }
+
 // The list walk is VALU-bound and compiled for 7 waves per SIMD (72 VGPRs, no spill; 8 would spill and lose).  The
 // BVH walks are bound by the CU's L1 and indifferent to 6..8 waves: 8 (64 VGPRs) for the plain walks, 6 for the
 // yielding one, which keeps its walk state in registers through the shading code.  All launch with a small LDS plan.

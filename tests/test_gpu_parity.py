@@ -492,6 +492,33 @@ def test_material_stream_build_is_bit_identical(tmp_path):
         assert int(a["rays"]) == int(b["rays"]) and np.array_equal(a["hist"], b["hist"])
 
 
+def test_two_paths_per_lane_is_bit_identical(gpu, orc):
+    """Option paths_per_lane = 2 (k_trace2: two paths in every lane share the metal/dielectric pass, the cooperative rounds and
+    the record fetches of the list walk; measured slower, profiles/r02_two_paths.txt, hence not the default) regroups work,
+    never arithmetic: sums, ray counts and depth histograms equal the oracle's and the default kernel's bit for bit, also
+    with path counts that leave path slots empty, with three sample tiles, and at depth limits 0 and 2."""
+    for world, (w, h, spp, md) in (("cornell", (96, 96, 9, 50)), ("two_boxes", (64, 64, 5, 50)), ("spheres4", (200, 100, 6, 50)),
+                                   ("cornell", (7, 3, 1, 50)), ("cornell", (65, 1, 2, 0)), ("cornell", (33, 31, 7, 2))):
+        s, cam = WORLDS[world][0]()
+        s.nodes = None
+        gpu.upload_scene(s); gpu.set_camera(cam)
+        out = {}
+        try:
+            for ppl in (1, 2):
+                gpu.set_option("paths_per_lane", ppl)
+                out[ppl] = gpu.render(w, h, spp, md, 91, capi.FLAG_ACCEL_LIST)
+            gpu.set_option("max_paths", max(1024, 2 * w * h + 3))
+            out["tiled"] = gpu.render(w, h, spp, md, 91, capi.FLAG_ACCEL_LIST)
+        finally:
+            gpu.set_option("paths_per_lane", 1); gpu.set_option("max_paths", 1 << 30)
+        osum, ost = orc.trace(s, cam, w, h, spp, md, 91, capi.FLAG_ACCEL_LIST)
+        for key in (2, "tiled"):
+            H.assert_bits(out[key]["sum"], osum, f"{world} {w}x{h}@{spp} paths_per_lane 2 ({key}) vs oracle")
+            H.assert_bits(out[key]["sum"], out[1]["sum"], f"{world} {w}x{h}@{spp} paths_per_lane 2 ({key}) vs 1")
+            assert out[key]["stats"].rays == ost.rays == out[1]["stats"].rays
+            assert list(out[key]["stats"].depth_hist) == list(out[1]["stats"].depth_hist)
+
+
 @pytest.mark.parametrize("world", list(WORLDS))
 def test_engines_identical(gpu, orc, world):
     """The persistent engine (k_trace, default) and the wavefront engine (k_bounce per depth) run the same per-path
