@@ -110,22 +110,25 @@ __device__ __forceinline__ float div_by(const DivBy &q, float x)
 
 __device__ __forceinline__ f3 normalize(f3 a)                                                         // Vec3.h:100-103
 {
-    float l2 = dot(a, a);
-    float l = MIRT_SQRT(l2);
-    // three quotients, one denominator: div_by when every active lane is inside its range -- all components in
-    // [2^-40, 2^19] in magnitude, the largest at least 2^-19, which puts l in [2^-20, 2^20]; exact zeros, NaN and
-    // out-of-range vectors take the plain divides, whole wave
-    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
-    const float hi = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az), lo = __builtin_fminf(__builtin_fminf(ax, ay), az);
-    const bool fast = (lo >= 0x1p-40f) & (hi >= 0x1p-19f) & (hi <= 0x1p19f) & (ax == ax) & (ay == ay) & (az == az);
+    const float l2 = dot(a, a);
+    // three quotients, one denominator: div_by when every active lane is inside its range -- every component at least 2^-40 in
+    // magnitude and the squared length in [2^-36, 2^36], which puts the length in [2^-18, 2^18], the largest component in
+    // [2^-19, 2^19], and the squared length inside the lean square root's range; a NaN component makes l2 NaN and fails the
+    // compares.  Exact zeros, NaN and out-of-range vectors take the plain divides and the general square root, whole wave.
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const bool fast = (lo >= 0x1p-40f) & (l2 >= 0x1p-36f) & (l2 <= 0x1p36f);
     f3 r;
     if (__ballot(!fast) == 0ull) {
+        const float l = (MIRT_TEXP & 2) ? __builtin_amdgcn_sqrtf(l2) : sqrt_in_range(l2);
         const DivBy by_l = div_prepare(l);
         r = mk(div_by(by_l, a.x), div_by(by_l, a.y), div_by(by_l, a.z));
-    } else r = mk(a.x / l, a.y / l, a.z / l);
-    if ((l == 0.0f) | __builtin_isinf(l2)) {                  // both special cases behind one, almost never taken, branch
-        const float q = (l == 0.0f) ? 0.0f : __builtin_nanf("");
-        r = mk(q, q, q);
+    } else {
+        const float l = MIRT_SQRT(l2);
+        r = mk(a.x / l, a.y / l, a.z / l);
+        if ((l == 0.0f) | __builtin_isinf(l2)) {              // both special cases behind one, almost never taken, branch
+            const float q = (l == 0.0f) ? 0.0f : __builtin_nanf("");
+            r = mk(q, q, q);
+        }
     }
     return r;
 }
@@ -424,6 +427,14 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
 
 // ----------------------------------------------------------------------------- Optics.h
 __device__ __forceinline__ f3 reflect(f3 v, f3 n) { return v - scale(n, 2 * dot(v, n)); }            // Optics.h:8-12
+// dt: dot(v, n), which the caller may already hold (see scatter_finish)
+__device__ __forceinline__ bool refract_dt(f3 v, f3 n, float dt, float ni_over_nt, f3 &refracted)     // Optics.h:16-22
+{
+    float disc = 1.0f - ni_over_nt * ni_over_nt * (1 - dt * dt);
+    bool ret = disc > 0;
+    if (ret) refracted = scale(v - scale(n, dt), ni_over_nt) - scale(n, MIRT_SQRT(disc));
+    return ret;
+}
 __device__ __forceinline__ bool refract(f3 v, f3 n, float ni_over_nt, f3 &refracted)                 // Optics.h:14-23
 {
     float dt = dot(v, n);
@@ -520,7 +531,11 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
             float dn = dot(uv, nrm);
             if (dn > 0) { outward = neg(nrm); ni_over_nt = ior; cosine = ior * dn; }
             else { outward = nrm; ni_over_nt = m.inv_ior; cosine = -dn; }
-            if (refract(uv, outward, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.r0);
+            // dot(uv, outward) without a second dot product: outward is nrm or 0 - nrm, and with dn > 0 the products of the
+            // negated normal are the negated products (a zero component only changes the sign of a zero term, which a non-zero
+            // sum does not see), so the sum is -dn bit for bit; with dn <= 0 (or NaN) it is the same expression as dn
+            const float dt = dn > 0 ? -dn : dn;
+            if (refract_dt(uv, outward, dt, ni_over_nt, refracted)) reflect_prob = schlick(cosine, m.r0);
             else reflect_prob = 1.0f;
             o.dir = (unorm < reflect_prob) ? refl : refracted;
             o.alive = true;
