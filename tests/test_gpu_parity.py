@@ -434,7 +434,7 @@ def test_axis_parallel_rays(gpu, orc, world):
     d[mix, rng.integers(0, 3, mix.sum())] = rng.standard_normal(mix.sum()).astype(np.float32)
     d[::7] = np.where(d[::7] == 0, np.float32(-0.0), d[::7])       # both signs of zero
     o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
-    assert (o["prim"] >= 0).sum() > 500
+    assert (o["prim"] >= 0).sum() > 250
     H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list")
     # the reference's BVH walk culls a ray that only grazes a node box (AABB.cpp:17 uses <=), so it misses some
     # edge and corner hits the list finds; the device does the same in the same cases
@@ -592,7 +592,7 @@ def test_random_scenes(gpu, orc, seed):
     org, d = H.ray_batch(8192, 40 + seed, extent=5.0)
     for flags in (0, capi.FLAG_ACCEL_LIST):
         o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
-        assert (o["prim"] >= 0).sum() > 500
+        assert (o["prim"] >= 0).sum() > 250
         H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags), o, f"seed {seed} flags {flags}")
     w, h = 72, 48
     for flags in (0, capi.FLAG_ACCEL_LIST):
@@ -600,6 +600,14 @@ def test_random_scenes(gpu, orc, seed):
         osum, ost = orc.trace(s, cam, w, h, 4, 50, seed, flags)
         H.assert_bits(g["sum"], osum, f"seed {seed} image flags {flags}")
         assert g["stats"].rays == ost.rays
+        if flags == capi.FLAG_ACCEL_LIST:                                  # the same list walk with two paths in every lane (k_trace2)
+            try:
+                gpu.set_option("paths_per_lane", 2)
+                g = gpu.render(w, h, 4, 50, seed, flags)
+            finally:
+                gpu.set_option("paths_per_lane", 1)
+            H.assert_bits(g["sum"], osum, f"seed {seed} image, two paths per lane")
+            assert g["stats"].rays == ost.rays
     olist, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
     s.nodes = None
     gpu.upload_scene(s)
