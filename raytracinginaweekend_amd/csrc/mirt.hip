@@ -545,9 +545,23 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             a.cursor = counts + batch * per_batch; a.hist = a.cursor + 1;
             // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim.  At most 512 ids: what a wave
             // still holds when the cursor runs dry is the tail of the launch (exits spread over 0.72 ms with 2048, 0.65 with 512)
-            const uint64_t waves = (uint64_t)max_grid * (MIRT_BLOCK / 64);
+            // A small launch runs on fewer workgroups per CU than fit: with only a few paths per lane the launch is as long as its
+            // longest chain of bounces, and every wave of a fuller SIMD advances more slowly.  Measured (profiles/r02_small_launches.txt):
+            // list walk, up to ~1.2 M paths: two or three workgroups per CU, about six paths per resident lane (Cornell 128^2@16
+            // 0.34 -> 0.24 ms, 1024^2 at 1 spp 0.51 -> 0.37 ms; between 1.2 M and 8 M paths the grid size measures within noise);
+            // BVH walks: four up to 512 k paths, five up to 4 M (485 spheres 1024^2 at 1 spp 0.92 -> 0.79 ms); the whole CU beyond.
+            uint32_t grid_cap = max_grid;
+            if (!c->blocks_per_cu) {
+                const uint64_t per_share = (uint64_t)c->n_cu * MIRT_BLOCK * 6;
+                uint64_t want = per_cu;
+                if (mode == 0) { if (a.n_paths <= 3 * per_share) want = std::max<uint64_t>(2, (a.n_paths + per_share - 1) / per_share); }
+                else if (a.n_paths <= (512u << 10)) want = 4;
+                else if (a.n_paths <= (4u << 20)) want = 5;
+                grid_cap = (uint32_t)c->n_cu * (uint32_t)std::min<uint64_t>(per_cu, want);
+            }
+            const uint64_t waves = (uint64_t)grid_cap * (MIRT_BLOCK / 64);
             a.claim = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, max_grid);
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, grid_cap);
             // Small launches (claims of 64: under 4096 paths per wave) would be bound by the claim counter -- one atomic word hands
             // out ~90 M claims a second, the list walk ends 140 M claims' worth of paths -- so there three quarters of a wave's fair
             // share are its own from the start, dealt in chunks of 64 ids round-robin over the waves (TraceArgs::own_chunks), and
@@ -556,7 +570,9 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             // dealt and at any grid size: 56 -> 75 ms), and claims are what evens that out.
             const uint64_t grid_waves = (uint64_t)grid * (MIRT_BLOCK / 64);
             a.grid_waves = (uint32_t)grid_waves;
-            a.own_chunks = a.claim == 64u ? (uint32_t)(a.n_paths / grid_waves / 64 * 6 / 8) : 0u;
+            // ... of the BVH walks, whose paths differ more in length and end fewer claims a second, three eighths (485 spheres
+            // 512^2@16: 2.68 -> 1.65 ms at equal grid, 1024^2@8: 2.89 -> 2.12 ms; none at all is slower again at 1200x800@16)
+            a.own_chunks = a.claim == 64u ? (uint32_t)(a.n_paths / grid_waves / 64 * (mode == 0 ? 6u : 3u) / 8) : 0u;
             a.first_claim = (uint32_t)(grid_waves * a.own_chunks * 64);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch], st));
             launch_trace(c, mode, a, grid, st);
