@@ -164,7 +164,10 @@ int         mirt_device_count(void);
  *                   0: wavefront formulation, one launch per bounce over compacted path queues.
  *                   Both produce the same bits.
  *                   (engine 0: single-colour scenes only; batches of at most 256 Mi paths)
- *  "blocks_per_cu"  workgroups per CU of the persistent grid (0 = occupancy query, default)
+ *  "blocks_per_cu"  workgroups per CU of the persistent grid (0, default: as many as fit for large launches, fewer for
+ *                   launches of few paths per lane)
+ *  "paths_per_lane" list walk of scenes without image textures: 1 (default) one path per lane; 2: two paths in every
+ *                   lane, which share the passes that few lanes need (measured slower, kept under test).  Same image.
  *  "walk_yield"     near-first BVH walks in resumable slices: a wave leaves the walk loop once this many of its
  *                   lanes have finished, shades them and resumes the others (1..64); 0: every wave waits for its
  *                   longest walk; -1 (default): the library's choice, currently 0 at every size.  Same image.
