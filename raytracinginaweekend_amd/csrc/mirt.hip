@@ -543,16 +543,14 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             const uint32_t ns = std::min<uint32_t>(S, spp_begin + spp_count - s0);
             a.pix0 = pix0; a.npix = np; a.spp0 = s0; a.n_paths = np * ns; a.by_npix = fastdiv_make(np);
             a.cursor = counts + batch * per_batch; a.hist = a.cursor + 1;
-            // ~32 claims per resident wave keep the end of the launch balanced; one atomic per claim.  At most 512 ids: what a wave
-            // still holds when the cursor runs dry is the tail of the launch (exits spread over 0.72 ms with 2048, 0.65 with 512)
             // A small launch runs on fewer workgroups per CU than fit: with only a few paths per lane the launch is as long as its
             // longest chain of bounces, and every wave of a fuller SIMD advances more slowly.  Measured (profiles/r02_small_launches.txt):
             // list walk, up to ~1.2 M paths: two or three workgroups per CU, about six paths per resident lane (Cornell 128^2@16
             // 0.34 -> 0.24 ms, 1024^2 at 1 spp 0.51 -> 0.37 ms; between 1.2 M and 8 M paths the grid size measures within noise);
             // BVH walks: four up to 512 k paths, five up to 4 M (485 spheres 1024^2 at 1 spp 0.92 -> 0.79 ms); the whole CU beyond.
             uint32_t grid_cap = max_grid;
+            const uint64_t per_share = (uint64_t)c->n_cu * MIRT_BLOCK * 6;
             if (!c->blocks_per_cu) {
-                const uint64_t per_share = (uint64_t)c->n_cu * MIRT_BLOCK * 6;
                 uint64_t want = per_cu;
                 if (mode == 0) { if (a.n_paths <= 3 * per_share) want = std::max<uint64_t>(2, (a.n_paths + per_share - 1) / per_share); }
                 else if (a.n_paths <= (512u << 10)) want = 4;
@@ -560,19 +558,30 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
                 grid_cap = (uint32_t)c->n_cu * (uint32_t)std::min<uint64_t>(per_cu, want);
             }
             const uint64_t waves = (uint64_t)grid_cap * (MIRT_BLOCK / 64);
-            a.claim = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(64, (a.n_paths / (waves * 32)) & ~63ull));
+            // How a batch's path ids reach the waves (profiles/r02_small_launches.txt).  Two things pull apart: a single atomic word
+            // hands out only ~90 M claims a second, while the list walk ends 10..25 G paths a second -- so claims must be large, or
+            // part of every wave's fair share must be its own from the start (TraceArgs::own_chunks: chunks of 64 ids dealt
+            // round-robin over the waves, only the rest is claimed); but waves do not advance at equal speed, so what is dealt
+            // statically or claimed in large pieces lengthens the end of the launch (Cornell 1024^2@512 with equal static shares,
+            // however dealt and at any grid size: 56 -> 75 ms).  Measured optimum by launch size:
+            //   list walk   up to ~1.2 M paths (the capped grid above): claims of 64, six eighths of the share static;
+            //               up to 12 M: claims of 256, four eighths static; up to 32 M: 256, three eighths (Cornell 1024^2@16:
+            //               2.45 -> 2.12 ms, 4 spheres 1200x800@10: 0.94 -> 0.64 ms); beyond: ~32 claims per wave, 256..512 ids, none static;
+            //   BVH walks   (longer paths of more uneven length): up to 6 M paths claims of 64 (40 M in trees of 64 Ki nodes and more,
+            //               whose walks are slower still), up to 64 M of 128, three eighths static in both (485 spheres 1200x800@32: 5.55 -> 5.03 ms); beyond: claims of 256, none static.
+            uint32_t own_eighths = 0;
+            if (mode == 0) {
+                if (a.n_paths <= 3 * per_share) { a.claim = 64; own_eighths = 6; }
+                else if (a.n_paths <= (32u << 20)) { a.claim = 256; own_eighths = a.n_paths <= (12u << 20) ? 4 : 3; }
+                else a.claim = (uint32_t)std::min<uint64_t>(512, std::max<uint64_t>(256, (a.n_paths / (waves * 32)) & ~63ull));
+            } else {
+                if (a.n_paths <= (64u << 20)) { a.claim = a.n_paths <= ((a.sc.n_nodes >= 65536u ? 40u : 6u) << 20) ? 64 : 128; own_eighths = 3; }
+                else a.claim = 256;
+            }
             const uint32_t grid = (uint32_t)std::min<uint64_t>(((uint64_t)a.n_paths + a.claim - 1) / a.claim, grid_cap);
-            // Small launches (claims of 64: under 4096 paths per wave) would be bound by the claim counter -- one atomic word hands
-            // out ~90 M claims a second, the list walk ends 140 M claims' worth of paths -- so there three quarters of a wave's fair
-            // share are its own from the start, dealt in chunks of 64 ids round-robin over the waves (TraceArgs::own_chunks), and
-            // only the rest is claimed (4-sphere 200x100@100: 0.59 -> 0.37 ms, Cornell 1024^2@16: 3.40 -> 2.53 ms).  Larger launches
-            // keep claiming everything: waves do not advance at equal speed (Cornell 1024^2@512 with equal shares for all, however
-            // dealt and at any grid size: 56 -> 75 ms), and claims are what evens that out.
             const uint64_t grid_waves = (uint64_t)grid * (MIRT_BLOCK / 64);
             a.grid_waves = (uint32_t)grid_waves;
-            // ... of the BVH walks, whose paths differ more in length and end fewer claims a second, three eighths (485 spheres
-            // 512^2@16: 2.68 -> 1.65 ms at equal grid, 1024^2@8: 2.89 -> 2.12 ms; none at all is slower again at 1200x800@16)
-            a.own_chunks = a.claim == 64u ? (uint32_t)(a.n_paths / grid_waves / 64 * (mode == 0 ? 6u : 3u) / 8) : 0u;
+            a.own_chunks = (uint32_t)(a.n_paths / grid_waves / 64 * own_eighths / 8);
             a.first_claim = (uint32_t)(grid_waves * a.own_chunks * 64);
             if (timed) HIPCHK(c, hipEventRecord(c->ev_pool[2 * batch], st));
             launch_trace(c, mode, a, grid, st);

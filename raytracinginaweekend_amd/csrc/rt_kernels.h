@@ -875,6 +875,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         // advance at very different speeds, 0.3 to 2.7 paths/us within one launch (tools/wave_dump.py: the oldest wave is served
         // first), and the last exits of a 28.8 ms launch are spread over 1.2 ms; but shrinking to 64 ids cost 5 ms at the claim
         // counter, and floors of 256..1024 ids left the time where it was.)
+        // (Dealing a workgroup's claim to its waves 64 ids at a time through a pool in LDS -- one global atomic per 256..512 ids
+        // and still the fine grain -- was built and measured too: no faster than waves that keep their whole claim.)
         uint32_t b = 0;
         if (lane == 0) b = a.first_claim + atomicAdd(a.cursor, a.claim);
         b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
