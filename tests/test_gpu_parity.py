@@ -562,6 +562,29 @@ def test_persistent_engine_edges(gpu, orc):
         assert hist[0] == w * h * spp and sum(hist) == ost.rays and all(a >= b for a, b in zip(hist, hist[1:])) and not any(hist[md + 1:])
 
 
+def test_launch_regimes_by_size(gpu, orc):
+    """render_persistent picks grid size, claim size and the statically dealt share of the path ids by launch size
+    (profiles/r02_small_launches.txt).  Every path id of a batch must be traced exactly once in each regime: sums, ray counts
+    and path-length histograms against the oracle for the list walk (capped grid with claims of 64; claims of 256 with four and
+    with three eighths static; path counts that are no multiple of anything) and for the BVH walk (capped grid; claims of 64
+    and of 128 with three eighths static)."""
+    s, cam = scene.cornell_box(1.0)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    for (w, h, spp) in ((640, 480, 3), (1021, 509, 5), (1024, 1024, 13)):          # 0.9 M, 2.6 M, 13.6 M paths
+        g = gpu.render(w, h, spp, 50, 9, capi.FLAG_ACCEL_LIST, want=("sum",))
+        osum, ost = orc.trace(s, cam, w, h, spp, 50, 9, capi.FLAG_ACCEL_LIST)
+        H.assert_bits(g["sum"], osum, f"list walk {w}x{h}@{spp}")
+        assert g["stats"].rays == ost.rays and list(g["stats"].depth_hist)[0] == w * h * spp
+    s, cam = scene.spheres_world(1.5)
+    capi.build_bvh(s)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    for (w, h, spp) in ((600, 400, 2), (600, 400, 11), (1203, 797, 8)):              # 0.5 M, 2.6 M, 7.7 M paths
+        g = gpu.render(w, h, spp, 50, 9, capi.FLAG_ACCEL_ORDERED, want=("sum",))
+        osum, ost = orc.trace(s, cam, w, h, spp, 50, 9, capi.FLAG_ACCEL_ORDERED)
+        H.assert_bits(g["sum"], osum, f"near-first walk {w}x{h}@{spp}")
+        assert g["stats"].rays == ost.rays and list(g["stats"].depth_hist)[0] == w * h * spp
+
+
 def random_scene(seed):
     """Spheres, rotated rects of every alignment and rotated cubes with all four material kinds, at random places."""
     rng = np.random.default_rng(seed)
