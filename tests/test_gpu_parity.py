@@ -440,17 +440,22 @@ def test_axis_parallel_rays(gpu, orc, world):
     # edge and corner hits the list finds; the device does the same in the same cases
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
     H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order")
-    # near-first: same node boxes under the same rule (objects themselves are not box-culled on a graze, as in the
-    # reference), so the same closest t; only the winner of an exact tie may differ
+    # near-first: the whole hit record equals the oracle's walk of the same tree in the same order.  Against the
+    # reference-order walk the closest t is the same except on grazing rays: the reference's walk, having met the floor
+    # first, culls the box of a ball that touches the floor there (AABB.cpp:17, `<=`) and so misses the ball's hit an ulp
+    # nearer; the near-first walk meets the ball first and agrees with the list.  A few rays of this lattice in 16 384.
     g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
-    H.assert_bits(g["t"], o1["t"], "axis-parallel near-first t")
+    o2, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
+    H.assert_hits_equal(g, o2, "axis-parallel near-first")
     assert np.array_equal(g["prim"] >= 0, o1["prim"] >= 0)
+    differs = g["t"].view(np.uint32) != o1["t"].view(np.uint32)
+    assert differs.sum() <= 8 and np.array_equal(g["t"].view(np.uint32)[differs], o["t"].view(np.uint32)[differs]) and (g["t"][differs] < o1["t"][differs]).all()
 
 
 def test_million_spheres(gpu, orc):
     """BASELINE config 4 (the generator of World.cpp:36-58 extended to a 1000x1000 grid, ~1M spheres): the host-built
-    SAH tree is walked in the reference's order by the oracle and by the device (bit-exact hits and image), and
-    near-first by the device (same closest t, same image: no coplanar surfaces here)."""
+    SAH tree is walked in the reference's order and near-first by the oracle and by the device (bit-exact hits and images,
+    each order against its own twin; the two orders agree on the closest t of the ray batch and on all but isolated pixels)."""
     s, cam = scene.spheres_world(1.5, grid=500, look_from=(26.0, 6.0, 6.0))
     assert s.n_objects > 900000
     depth = capi.build_bvh(s)
@@ -464,11 +469,16 @@ def test_million_spheres(gpu, orc):
     g2 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
     H.assert_bits(g2["t"], o["t"], "1M near-first t"); assert np.array_equal(g2["prim"], o["prim"])
     w, h = 96, 64
-    osum, ost = orc.trace(s, cam, w, h, 2, 50, 11, 0)
-    for flags in (0, capi.FLAG_ACCEL_ORDERED):
+    sums = []
+    for flags in (0, capi.FLAG_ACCEL_ORDERED):                   # each walk against the oracle's walk in the same order
+        osum, ost = orc.trace(s, cam, w, h, 2, 50, 11, flags)
         g = gpu.render(w, h, 2, 50, 11, flags)
         H.assert_bits(g["sum"], osum, f"1M image flags={flags}")
         assert g["stats"].rays == ost.rays
+        sums.append(g["sum"])
+    # the two orders see the same surfaces; they may disagree only on the reference sphere test's false positives (a ray that
+    # passes just outside a sphere is accepted when its box happens to be visited): isolated pixels
+    assert (np.abs(sums[0] - sums[1]).max(axis=2) > 0).sum() <= 4
 
 
 def test_material_stream_build_is_bit_identical(tmp_path):
