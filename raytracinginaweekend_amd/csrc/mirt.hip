@@ -566,7 +566,10 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
             // however dealt and at any grid size: 56 -> 75 ms).  Measured optimum by launch size:
             //   list walk   up to ~1.2 M paths (the capped grid above): claims of 64, six eighths of the share static;
             //               up to 12 M: claims of 256, four eighths static; up to 32 M: 256, three eighths (Cornell 1024^2@16:
-            //               2.45 -> 2.12 ms, 4 spheres 1200x800@10: 0.94 -> 0.64 ms); beyond: ~32 claims per wave, 256..512 ids, none static;
+            //               2.45 -> 2.12 ms, 4 spheres 1200x800@10: 0.94 -> 0.64 ms); beyond: ~32 claims per wave, 256..512 ids, none static
+            //               (what a wave still holds when the cursor runs dry is the tail of the launch: exits spread over 0.72 ms with
+            //               claims of 2048, 0.65 with 512; claims of 256 throughout gain 0.7 % on Cornell 1024^2@128 and lose 38 % on the
+            //               4-sphere scene at 1200x800@500, whose 29 G paths a second then ask the counter for 115 M claims a second);
             //   BVH walks   (longer paths of more uneven length): up to 6 M paths claims of 64 (40 M in trees of 64 Ki nodes and more,
             //               whose walks are slower still), up to 64 M of 128, three eighths static in both (485 spheres 1200x800@32: 5.55 -> 5.03 ms); beyond: claims of 256, none static.
             uint32_t own_eighths = 0;
