@@ -1383,6 +1383,7 @@ __device__ __forceinline__ void trace_body2(const TraceArgs &a)
     bool live[2] = { false, false };
     f3 o[2] = { mk(0, 0, 0), mk(0, 0, 0) }, d[2] = { mk(1, 1, 1), mk(1, 1, 1) }, thr[2] = { mk(1.0f, 1.0f, 1.0f), mk(1.0f, 1.0f, 1.0f) };
     uint32_t pid[2] = { 0, 0 }, pixel[2] = { 0, 0 }, sample[2] = { 0, 0 }, depth[2] = { 0, 0 };
+    bool odd = false;                                               // wave-uniform: parity of the iteration
 
     for (;;) {
         // ---- top up the stash: 64 camera rays by the whole wave (HomemadeRayTracer.cpp:114-131)
@@ -1482,9 +1483,12 @@ __device__ __forceinline__ void trace_body2(const TraceArgs &a)
                 else { hp[k] = s.emits ? thr[k] * s.emitted : scale(thr[k], 0.0f); done[k] = true; }   // an absorbed path: thr * (0,0,0), :173
             }
         }
-        const bool retry1 = md[0] & md[1];                           // both paths of the lane: path 1 meets its vertex again next time
+        // both paths of the lane need the pass: one is shaded, the other meets its vertex again next time -- path 1 in even
+        // iterations, path 0 in odd ones, so that neither starves in a scene of metal and glass only
+        const bool both = md[0] & md[1];
+        odd = !odd;
         if (md[0] | md[1]) {
-            const bool s1 = !md[0];
+            const bool s1 = md[1] & (!md[0] | odd);
             const MatRec *SM = mat_of(s1 ? mi[1] : mi[0]);
             const f3 din = s1 ? d[1] : d[0], pos = s1 ? hp[1] : hp[0], nrm = s1 ? hn[1] : hn[0], spt = s1 ? sp[1] : sp[0];
             const float su = s1 ? un[1] : un[0];
@@ -1500,7 +1504,7 @@ __device__ __forceinline__ void trace_body2(const TraceArgs &a)
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const bool rt = k == 1 && retry1;
+            const bool rt = both && ((k == 1) != odd);             // the path of the pair that was not shaded
             if (live[k] && done[k]) {
                 store_rad(a.rad, pid[k], hp[k]);
                 atomicAdd(&s_hist[depth[k] < 63u ? depth[k] : 63u], 1u);

@@ -527,6 +527,21 @@ def test_two_paths_per_lane_is_bit_identical(gpu, orc):
             H.assert_bits(out[key]["sum"], out[1]["sum"], f"{world} {w}x{h}@{spp} paths_per_lane 2 ({key}) vs 1")
             assert out[key]["stats"].rays == ost.rays == out[1]["stats"].rays
             assert list(out[key]["stats"].depth_hist) == list(out[1]["stats"].depth_hist)
+    # metal and glass only: every vertex wants the shared pass, so in most lanes both paths do and one of them must wait
+    s = scene.FlatScene(ambient=(0.7, 0.8, 1.0))
+    mats = [s.metal((0.8, 0.6, 0.4), 0.3), s.dielectric(1.5), s.metal((0.9, 0.9, 0.9), 0.0)]
+    for i, c in enumerate(((0.0, -100.5, -1.0), (0.0, 0.0, -1.0), (1.0, 0.0, -1.0), (-1.0, 0.0, -1.0), (0.3, 0.4, 0.2))):
+        s.sphere(c, 100.0 if i == 0 else (0.5 if i < 4 else 0.2), mats[i % 3])
+    cam = scene.make_camera((0.0, 0.6, 2.5), (0.0, 0.0, -1.0), 40.0, 0.0, 1.5)
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    try:
+        gpu.set_option("paths_per_lane", 2)
+        g = gpu.render(90, 60, 7, 50, 5, capi.FLAG_ACCEL_LIST)
+    finally:
+        gpu.set_option("paths_per_lane", 1)
+    osum, ost = orc.trace(s, cam, 90, 60, 7, 50, 5, capi.FLAG_ACCEL_LIST)
+    H.assert_bits(g["sum"], osum, "metal and glass only, paths_per_lane 2")
+    assert g["stats"].rays == ost.rays
 
 
 @pytest.mark.parametrize("world", list(WORLDS))
