@@ -70,7 +70,7 @@ struct mirt_ctx {
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
     DevBuf d_queues, d_rad, d_counts, d_len, d_tmp_sum, d_tmp_pix, d_tmp_rgba;
-    uint64_t max_paths = 1ull << 30;        // 1 Gi paths per batch = 17 GB of radiance slots when fully used (a batch costs ~0.3 ms of tail)
+    uint64_t max_paths = 1ull << 30;        // 1 Gi paths per batch = 12.9 GB of radiance slots when fully used (a batch costs ~0.3 ms of tail)
     bool time_launches = false;
     uint32_t blocks_per_cu = 0;             // 0: as many workgroups per CU as the occupancy query reports
     uint32_t lds_budget = 4u * 1024u;      // per workgroup; takes effect at the next mirt_upload_scene

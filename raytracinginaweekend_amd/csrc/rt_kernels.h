@@ -13,7 +13,7 @@
 //
 // A path contributes radiance exactly once, at the vertex where it ends (emission is non-zero
 // only on DiffuseLight, which never scatters, Materials.cpp:260-264, and on a miss,
-// HomemadeRayTracer.cpp:186), so each path writes one float4 into rad[] when it terminates and
+// HomemadeRayTracer.cpp:186), so each path writes one 12-byte slot of rad[] when it terminates and
 // k_accumulate adds the samples of a pixel in sample order -- the same order as the reference's
 // `col += Sample(r, 0)` loop (HomemadeRayTracer.cpp:126-133).  No float atomics, no run-to-run
 // variation, and no dependence on which lane or launch traced a path.
@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_bounce(BounceArgs a)
 // path queues.  Each lane owns one path and walks it bounce after bounce; when the path ends, the lane
 // takes a fresh camera ray.  Camera rays are produced 64 at a time by the whole wave (full lanes, coherent
 // pixels) into a small per-wave LDS stash, so refilling a lane costs a few LDS reads; path ids come from a
-// global cursor in claims of a few hundred, one atomic per claim.  Nothing but the scene and the 16-byte
+// global cursor in claims of a few hundred, one atomic per claim.  Nothing but the scene and the 12-byte
 // radiance slot per path touches HBM, and one launch serves a whole batch.
 // Every path's arithmetic and Philox keys are those of k_bounce, so the two engines give identical images.
 struct TraceArgs {
