@@ -125,6 +125,8 @@ def test_scatter_known_answers():
     assert np.array_equal(o["atten"][2], [1, 1, 1])
     # straight down into glass with unorm 0.5 >= schlick(1, 1.5) = 0.04: refracted, undeviated: eta*(v - n*dt) - n*sqrt(disc) = (0,-1,0)
     assert np.allclose(o["dir"][2], [0, -1, 0], atol=1e-6)
+    light_back = orc.scatter_batch(s, hits[0:1], [[0, 1, 0]], draws[0:1])                  # a light emits from both faces (Materials.cpp:260-264)
+    assert light_back["alive"][0] == 0 and np.array_equal(light_back["emit"][0], [15, 15, 15])
     lam_back = orc.scatter_batch(s, hits[1:2], [[0, 1, 0]], draws[1:2])
     assert lam_back["alive"][0] == 0 and lam_back["consumed"][0] == 3   # one-sided (Materials.cpp:32), draws still consumed
 
