@@ -67,7 +67,9 @@ __global__ void k(float *out, unsigned long long *cyc, float a, float b)
 #define T31(u) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(u) : "v"(a) : "vcc");
 #define T32(u) asm volatile("v_mov_b32 %0, %1" : "=v"(u) : "v"(__float_as_uint(a)));
 #define T33(u) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(u) : "v"(a), "v"(b));
-            double dd;
+#define T34(u) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(((unsigned long long)u << 32) | u), "v"(k64) : "vcc");
+#define T35(u) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cmp_eq_f32 s[20:21], %0, %1" : : "v"(u), "v"(a) : "vcc", "s20", "s21");
+            double dd; const unsigned long long k64 = ((unsigned long long)__float_as_uint(a) << 32) | __float_as_uint(b);
             if (OP == 20) { MIX(T20(u0), T20(u1), T20(u2), T20(u3)) }
             if (OP == 21) { MIX(T21(u0), T21(u1), T21(u2), T21(u3)) }
             if (OP == 22) { MIX(T22(u0), T22(u1), T22(u2), T22(u3)) }
@@ -82,6 +84,8 @@ __global__ void k(float *out, unsigned long long *cyc, float a, float b)
             if (OP == 31) { MIX(T31(u0), T31(u1), T31(u2), T31(u3)) }
             if (OP == 32) { MIX(T32(u0), T32(u1), T32(u2), T32(u3)) }
             if (OP == 33) { MIX(T33(u0), T33(u1), T33(u2), T33(u3)) }
+            if (OP == 34) { MIX(T34(u0), T34(u1), T34(u2), T34(u3)) }
+            if (OP == 35) { MIX(T35(u0), T35(u1), T35(u2), T35(u3)) }
             x0 = __uint_as_float(u0); x1 = __uint_as_float(u1); x2 = __uint_as_float(u2); x3 = __uint_as_float(u3);
         } else if (OP == 7) {
 #define S7(x) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p2##x) : "v"(pa));
@@ -127,6 +131,7 @@ int main(int argc, char **argv)
         run<24>("+4 v_cndmask_b32", 16); run<25>("+4 v_cmp_lt_f32", 16); run<26>("+4 v_bitop3_b32", 16); run<27>("+4 v_mul_f32", 16); run<28>("+4 v_sqrt_f32", 16);
         run<29>("+4 v_cvt_f64_u32 (+add)", 16); run<30>("+4 v_div_fixup_f32", 16); run<31>("+4 v_div_scale_f32", 16); run<32>("+4 v_mov_b32", 16); run<33>("+4 v_max3_f32", 16);
     }
+    if (argc > 1 && atoi(argv[1]) == 34) { run<9>("12 v_add_f32", 12); run<34>("+4 v_cmp_lt_u64", 16); run<35>("+4 (v_cmp_lt_f32; v_cmp_eq_f32)", 20); run<25>("+4 v_cmp_lt_f32", 16); }
     if (argc > 1 && atoi(argv[1]) == 6) run<6>("v_add_f32 + s_add", 32);
     if (argc > 1 && atoi(argv[1]) == 7) run<7>("v_pk_add_f32", 16);
     return 0;
