@@ -381,8 +381,10 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
 {
     int32_t best = -1;
     Stack stk(sc, v);
+    // A finished walk is cur == MIRT_CHILD_NONE (the root of an empty tree already is): the three questions the loop asks the
+    // wave -- who stands on a node, who on an object, who is still walking -- are then one compare of `cur` each, and a
+    // ballot of a plain compare is that compare (a ballot of a flag carried around the loop costs a select and a compare more).
     int32_t cur = sc.root;
-    bool act = cur != MIRT_CHILD_NONE;
     const PrimRec *P = PLDS ? v.prims : sc.prims;
     const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
     const uint2 *const objs = sgpr_pin(sc.objs);
@@ -390,7 +392,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     leaf_want = sgpr_pin(leaf_want);
     const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
     for (;;) {
-        if (act && cur >= 0) {
+        if (cur >= 0) {
             Node2 n;                                                      // always from memory: staging the top levels in LDS measured neutral, and the
             const GlobalF4 g = (GlobalF4)(nodes2 + cur);                  // per-lane choice between two address spaces costs flat loads
             const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
@@ -406,12 +408,12 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                 cur = left_first ? n.left : n.right;
             } else if (hl) cur = n.left;
             else if (hr) cur = n.right;
-            else if (stk.sp == 0) act = false;
+            else if (stk.sp == 0) cur = MIRT_CHILD_NONE;
             else cur = stk.pop();
         }
-        const bool at_leaf = act && cur < 0;
+        const bool at_leaf = (uint32_t)cur > (uint32_t)MIRT_CHILD_NONE;  // negative and not the end mark: ~object
         const unsigned long long lm = wave_mask(at_leaf);
-        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(act && cur >= 0) == 0ull)) {
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
             if (at_leaf) {
                 uint32_t first = (uint32_t)~cur, cnt = 1;
                 if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
@@ -419,10 +421,10 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                     float t;
                     if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
                 }
-                if (stk.sp == 0) act = false; else cur = stk.pop();
+                if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
         }
-        if (wave_mask(act) == 0ull) break;
+        if (wave_mask(cur != MIRT_CHILD_NONE) == 0ull) break;
     }
     return best;
 }
