@@ -79,7 +79,7 @@ struct mirt_ctx {
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
     uint32_t leaf_wait = MIRT_LEAF_WANT;   // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2)
     int32_t walk_yield = -1;                // near-first walks in slices that end when this many lanes of a wave have finished;
-                                            // 0: off, -1 (default): 56 for scenes of 65536 objects or more (+10 % on 1M spheres, -7 % on 485)
+                                            // 0: off, -1 (default): 56 for batches of 2 Mi paths or more
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
     uint32_t stack_lds = 4;                // traversal-stack levels kept in LDS (1 KiB each; 4 measured best with the wave-synchronous walk, 1-8 within 3 %); likewise
@@ -469,11 +469,14 @@ static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_sum, hipStream_t st, mirt_stats *stats,
                              int mode, uint32_t spp_begin, uint32_t spp_count, bool one_spp, const Workspace *fixed = nullptr)
 {
-    const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : 0u;   // -1 (default) = 0: since the walk became wave-synchronous the plain form wins at every size measured
-    if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
     const uint64_t npix_total = (uint64_t)p->width * p->height;
     uint64_t cap = std::min<uint64_t>(c->max_paths, npix_total * spp_count);
     if (fixed) cap = std::min<uint64_t>(cap, fixed->rad_paths);
+    // -1 (default) = 56 for batches of 2 Mi paths or more: with the resumable walk compiled for 8 waves per SIMD like the plain
+    // one (its state costs 3-4 dwords of scratch) the slices pay from ~4 M paths on (485 spheres 1200x800@500 +13 %, 1 M spheres
+    // 1920x1080@128 +10 %; 52/56/60/62 lanes: within 1 % / best / -1 % / -7 %); launches of ~1 M paths and fewer are 4 % faster plain
+    const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : ((c->walk_yield < 0 && cap >= (2ull << 20)) ? 56u : 0u);
+    if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
     const size_t capq = (size_t)npix_b * S;

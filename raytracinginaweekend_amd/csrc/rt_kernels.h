@@ -437,8 +437,9 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
 struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
 
 template <bool PLDS>
-__device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, bool &act, uint32_t want, uint32_t leaf_want)
+__device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, uint32_t want, uint32_t leaf_want)
 {
+    // a lane takes part while w.cur != MIRT_CHILD_NONE (closest_bvh2's end mark); lanes that hold no walk enter with the mark
     Stack stk(sc, v);
     stk.sp = w.sp;
     int32_t cur = w.cur;
@@ -448,9 +449,9 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
     leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
-    const unsigned long long entered = wave_mask(act);
+    const unsigned long long entered = wave_mask(cur != MIRT_CHILD_NONE);
     for (;;) {
-        if (act && cur >= 0) {
+        if (cur >= 0) {
             Node2 n;
             const GlobalF4 g = (GlobalF4)(nodes2 + cur);
             const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
@@ -466,26 +467,24 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
                 cur = left_first ? n.left : n.right;
             } else if (hl) cur = n.left;
             else if (hr) cur = n.right;
-            else if (stk.sp == 0) act = false;
+            else if (stk.sp == 0) cur = MIRT_CHILD_NONE;
             else cur = stk.pop();
         }
         // lanes on a leaf wait for company (closest_bvh2); a slice may end while they wait: the leaf is then the lane's `cur`
-        const bool at_leaf = act && cur < 0;
+        const bool at_leaf = (uint32_t)cur > (uint32_t)MIRT_CHILD_NONE;
         const unsigned long long lm = wave_mask(at_leaf);
-        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(act && cur >= 0) == 0ull)) {
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
             if (at_leaf) {
-                if (cur != MIRT_CHILD_NONE) {
-                    uint32_t first = (uint32_t)~cur, cnt = 1;
-                    if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
-                    for (uint32_t i = 0; i < cnt; ++i) {
-                        float t;
-                        if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
-                    }
+                uint32_t first = (uint32_t)~cur, cnt = 1;
+                if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    float t;
+                    if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
                 }
-                if (stk.sp == 0) act = false; else cur = stk.pop();
+                if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
         }
-        const unsigned long long still = wave_mask(act);
+        const unsigned long long still = wave_mask(cur != MIRT_CHILD_NONE);
         if (still == 0ull || (uint32_t)__popcll(entered & ~still) >= want) break;
     }
     w.cur = cur; w.sp = stk.sp;
@@ -829,7 +828,7 @@ __device__ __forceinline__ void wave_lds_sync()
 #define MIRT_LIST_WAVES 7
 #endif
 #ifndef MIRT_YIELD_WAVES
-#define MIRT_YIELD_WAVES 6   // the yielding walk keeps its walk state live through the shading code
+#define MIRT_YIELD_WAVES 8   // the yielding walk keeps its walk state live through the shading code: 3-4 dwords of scratch under the 64-register cap
 #endif
 // The kernel's arguments as they lie in the kernarg segment, behind a pointer the compiler cannot see through: what the
 // rare blocks of the loop read (camera, image geometry: ~40 words that only the stash refill needs) is then fetched there
@@ -894,8 +893,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     bool live = false;
     f3 o = mk(0, 0, 0), d = mk(0, 0, 1), thr = mk(1.0f, 1.0f, 1.0f);
     uint32_t pid = 0, pixel = 0, sample = 0, depth = 0;
-    WalkState ws; ws.cur = 0; ws.best = -1; ws.t_max = 0.0f; ws.sp = 0; ws.invd = mk(0, 0, 0);   // ACCEL 3 only
-    bool walking = false;
+    WalkState ws; ws.cur = MIRT_CHILD_NONE; ws.best = -1; ws.t_max = 0.0f; ws.sp = 0; ws.invd = mk(0, 0, 0);   // ACCEL 3 only; cur: no walk under way
 
     // ---- second stream: metal / dielectric vertices are parked (after their draws) and shaded 64 at a time
     constexpr bool DEFER = MIRT_DEFER_MD && ACCEL == 0 && !TEX;
@@ -1056,14 +1054,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         bool ready = live;                      // lanes whose closest hit is known in this iteration
         if constexpr (ACCEL == 3) {
             if (live) {
-                if (!walking) {
+                if (ws.cur == MIRT_CHILD_NONE) {                                   // a new ray: start its walk (a walk under way keeps its state)
                     ws.cur = a.sc.root; ws.best = -1; ws.t_max = 3.402823466e+38f; ws.sp = 0;
                     ws.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
-                    walking = true;
                 }
-                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, walking, a.slice_want, a.leaf_want);
+                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, a.slice_want, a.leaf_want);
             }
-            ready = live && !walking;
+            ready = live && ws.cur == MIRT_CHILD_NONE;
         }
         if (ready) {
             float t_max = 3.402823466e+38f;   // FLT_MAX
