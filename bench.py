@@ -213,7 +213,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label} {W}x{H} @{SPP} spp, depth {args.max_depth}, spp-sharded over {world} GPU(s)",
                        "name": args.workload, "seed": args.seed, "objects": int(sc.n_objects),
-                       "accel": f"list ({sc.n_prims} primitives through the scalar cache)" if list_walk else "own binned-SAH tree, near-first wave-synchronous walk",
+                       "accel": f"list ({sc.n_prims} primitives through the scalar cache)" if list_walk else "own binned-SAH tree, near-first wave-synchronous walk in resumable slices",
                        "spp_per_gpu": [sharding.spp_range(r, world, SPP)[1] for r in range(world)],
                        "engine": "persistent (k_trace)" if args.engine == 1 else "wavefront (k_bounce per depth)",
                        "collective": (("RCCL reduce (torch.distributed nccl)" if args.backend == "nccl" else "gloo reduce through host memory (rehearsal)") if world > 1 else "none")},
@@ -257,7 +257,7 @@ def rooflines(args, st, sc, list_walk, bound, ext_ms, ext_launches, n_inst, work
         k_flop = rays * flop_per_ray + samples * FLOP_PER_SAMPLE_FIXED
         k_bytes = samples * RAD_BYTES                          # the only per-path HBM traffic: one radiance slot
     else:
-        kname = "k_trace<true,false>" if list_walk else "k_trace_bvh<2,false,false>"
+        kname = "k_trace<true,false>" if list_walk else "k_trace_bvh<3,false,false>"   # 3: the near-first walk in resumable slices, the default from 2 Mi paths per batch
         if work is None:                                       # no oracle counters in this run (--no-cpu-baseline or N > 1): the committed ones
             work = committed_work(args.workload)
             note = "boxes/spheres per ray from profiles/r02_work_counters.json (no CPU sample in this run)"
