@@ -365,6 +365,31 @@ typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x4_t *GlobalF4;
 typedef const __attribute__((address_space(1))) u32x2_t *GlobalU2;
 
+// An object's primitive tested from a BVH leaf.  Left to itself the compiler sinks every field's load into the branch that uses it
+// (the sphere branch fetched r*r only after the kind had arrived and been tested: two memory round trips per leaf pass), so the
+// first 32 bytes -- all a sphere needs, one sector -- are fetched together and pinned in front of the test; what only rects and
+// rotated primitives need stays lazy.  Same arithmetic as prim_t on the record in memory.
+template <bool PLDS>
+__device__ __forceinline__ bool leaf_prim_t(const PrimRec *P, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t)
+{
+    if constexpr (PLDS) return prim_t(P[p], o, d, t_min, t_max, t);
+    else {
+        const GlobalF4 g = (GlobalF4)(P + p);
+        f32x4_t r0 = g[0], r1 = g[1];
+        asm volatile("" : "+v"(r0), "+v"(r1));
+        PrimRec pr;
+        pr.off[0] = r0.x; pr.off[1] = r0.y; pr.off[2] = r0.z; pr.info = __float_as_uint(r0.w);
+        pr.ga[0] = r1.x; pr.ga[1] = r1.y; pr.ga[2] = r1.z; pr.mat = __float_as_uint(r1.w);
+        // gb and rot are read by prim_t under the same two flags only
+        if (pr.info & 1u) { pr.gb[0] = P[p].gb[0]; pr.gb[1] = P[p].gb[1]; }        // rects only (the second sector of the record)
+        if (pr.info & 0x100u) {                                                   // rotation active
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pr.rot[k] = P[p].rot[k];
+        }
+        return prim_t(pr, o, d, t_min, t_max, t);
+    }
+}
+
 // Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
 // with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
 // current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
@@ -419,7 +444,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                 if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
                 for (uint32_t i = 0; i < cnt; ++i) {
                     float t;
-                    if (prim_t(P[first + i], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                    if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
@@ -479,7 +504,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
                 if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
                 for (uint32_t i = 0; i < cnt; ++i) {
                     float t;
-                    if (prim_t(P[first + i], o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                    if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
