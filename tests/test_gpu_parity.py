@@ -661,3 +661,16 @@ def test_random_scenes(gpu, orc, seed):
     gpu.upload_scene(s)
     g2 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
     H.assert_bits(g2["t"], olist["t"], f"seed {seed} near-first t")
+    # the library's own tree walked near-first, plain and in resumable slices (the default of large launches), against the
+    # oracle walking that tree in that order
+    capi.build_bvh(s)
+    gpu.upload_scene(s)
+    osum, ost = orc.trace(s, cam, w, h, 4, 50, seed, orc.FLAG_ACCEL_ORDERED)
+    try:
+        for wy in (0, 56):
+            gpu.set_option("walk_yield", wy)
+            g = gpu.render(w, h, 4, 50, seed, capi.FLAG_ACCEL_ORDERED)
+            H.assert_bits(g["sum"], osum, f"seed {seed} image, own tree near-first, walk_yield={wy}")
+            assert g["stats"].rays == ost.rays
+    finally:
+        gpu.set_option("walk_yield", -1)
