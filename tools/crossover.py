@@ -3,7 +3,7 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracinginaweekend_amd import capi, scene
-w, h, spp = 1200, 800, 16
+w, h, spp = 1200, 800, int(os.environ.get("MIRT_SPP", "16"))
 ctx = capi.Context(0)
 for grid in (1, 2, 3, 4, 5, 6, 8):
     s, cam = scene.spheres_world(w / h, grid=grid)
