@@ -66,6 +66,7 @@ struct mirt_ctx {
     mirt_camera cam{};
     DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_mdq, d_rdy;            // MIRT_DEFER_MD builds: per-wave queues of the second (metal/dielectric) stream
+    DevBuf d_sph4;                  // SceneDev::sph4
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -319,6 +320,17 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;
+    // scenes whose objects are all single unrotated spheres: the 16 bytes a leaf test reads, per object (rt_kernels.h sphere_leaf_t)
+    d.sph4 = nullptr;
+    bool all_spheres = single && s->n_prims == s->n_objects && s->n_prims > 0;
+    for (uint32_t p = 0; all_spheres && p < s->n_prims; ++p) all_spheres = prims[p].info == 0u && objs[p].x == p;
+    if (all_spheres) {
+        std::vector<float4> sph(s->n_prims);
+        for (uint32_t p = 0; p < s->n_prims; ++p) sph[p] = make_float4(prims[p].off[0], prims[p].off[1], prims[p].off[2], prims[p].ga[2]);
+        if (c->d_sph4.ensure(sph.size() * sizeof(float4))) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
+        HIPCHK(c, hipMemcpy(c->d_sph4.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
+        d.sph4 = (const float4 *)c->d_sph4.p;
+    }
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
     d.root = tree.root;
     for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];

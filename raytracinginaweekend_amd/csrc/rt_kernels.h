@@ -57,6 +57,7 @@ struct SceneDev {
     const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
     uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
     uint32_t single;                              // every object is one primitive: object index == primitive index
+    const float4  *sph4;                          // scenes of single unrotated spheres only (else NULL): (centre, r*r) per object -- all a leaf test reads, in ONE 16-byte access
     const uint2   *objs;   uint32_t n_objects;   // (first, count)
     const MatRec  *mats;   uint32_t n_mats;
     int32_t root;
@@ -390,6 +391,17 @@ __device__ __forceinline__ bool leaf_prim_t(const PrimRec *P, uint32_t p, f3 o, 
     }
 }
 
+// The leaf test of a scene whose objects are all single unrotated spheres (SceneDev::sph4): one 16-byte access per leaf instead of
+// the record's first sector in two, and prim_t with the kind known at compile time (no dispatch, no rotation check) -- the same
+// sphere arithmetic on the same operands.
+__device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t)
+{
+    const f32x4_t r = ((GlobalF4)sph4)[p];
+    PrimRec pr;
+    pr.off[0] = r.x; pr.off[1] = r.y; pr.off[2] = r.z; pr.info = 0u /* MIRT_PRIM_SPHERE, no rotation */; pr.ga[2] = r.w;
+    return prim_t(pr, o, d, t_min, t_max, t);
+}
+
 // Near-first traversal of the same tree (ACCEL 2).  A node carries both children's boxes; each is tested
 // with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
 // current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
@@ -414,6 +426,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
+    const float4 *const sph4 = sgpr_pin(sc.sph4);
     leaf_want = sgpr_pin(leaf_want);
     const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
     for (;;) {
@@ -440,11 +453,16 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
         const unsigned long long lm = wave_mask(at_leaf);
         if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
             if (at_leaf) {
-                uint32_t first = (uint32_t)~cur, cnt = 1;
-                if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
-                for (uint32_t i = 0; i < cnt; ++i) {
+                if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
                     float t;
-                    if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, t_max, t)) { t_max = t; best = ~cur; }
+                } else {
+                    uint32_t first = (uint32_t)~cur, cnt = 1;
+                    if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t;
+                        if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                    }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
@@ -473,6 +491,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
+    const float4 *const sph4 = sgpr_pin(sc.sph4);
     leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
     const unsigned long long entered = wave_mask(cur != MIRT_CHILD_NONE);
     for (;;) {
@@ -500,11 +519,16 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
         const unsigned long long lm = wave_mask(at_leaf);
         if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
             if (at_leaf) {
-                uint32_t first = (uint32_t)~cur, cnt = 1;
-                if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }          // Object::Hit, SimpleObject.cpp:73-83
-                for (uint32_t i = 0; i < cnt; ++i) {
+                if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
                     float t;
-                    if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = ~cur; }
+                } else {
+                    uint32_t first = (uint32_t)~cur, cnt = 1;
+                    if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t;
+                        if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                    }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
             }
