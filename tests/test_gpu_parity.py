@@ -317,6 +317,39 @@ def test_yielding_walk(gpu, orc):
         gpu.set_option("walk_yield", -1); gpu.set_option("max_paths", 1 << 30)
 
 
+def test_sphere_leaf_records_follow_the_scene(gpu, orc):
+    """Scenes whose objects are all single unrotated spheres get 16-byte leaf records (SceneDev::sph4, rt_kernels.h
+    sphere_leaf_t); any other scene keeps the generic records.  Uploaded in turn on ONE context -- spheres only, one rect among
+    the spheres, spheres only again (objects that list their primitives out of order are refused) -- each renders the oracle's image
+    bit for bit through the near-first walk, plain and in resumable slices."""
+    w, h = 64, 48
+    cam = scene.spheres_world(w / h)[1]
+
+    def check(s, label):
+        capi.build_bvh(s)
+        gpu.upload_scene(s); gpu.set_camera(cam)
+        osum, ost = orc.trace(s, cam, w, h, 4, 50, 5, orc.FLAG_ACCEL_ORDERED)
+        for wy in (0, 56):
+            gpu.set_option("walk_yield", wy)
+            g = gpu.render(w, h, 4, 50, 5, capi.FLAG_ACCEL_ORDERED)
+            H.assert_bits(g["sum"], osum, f"{label}, walk_yield={wy}")
+            assert g["stats"].rays == ost.rays
+
+    try:
+        s1 = scene.spheres_world(w / h)[0]
+        check(s1, "spheres only")
+        s2 = scene.spheres_world(w / h)[0]
+        s2.rect(scene.XZ_RECT, (0.0, 0.6, 0.0), (0.0, 0.0, 0.0), 3.0, 3.0, 0, s2.lambertian((0.7, 0.2, 0.2)))
+        check(s2, "one rect among the spheres")
+        s3 = scene.spheres_world(w / h)[0]                                 # objects out of primitive order are refused at upload, so
+        s3.obj_first[1], s3.obj_first[2] = s3.obj_first[2], s3.obj_first[1]; s3._arrays = None   # "object index == primitive index" holds
+        with pytest.raises(capi.MirtError):                                # wherever the sphere records are used
+            gpu.upload_scene(s3)
+        check(scene.spheres_world(w / h)[0], "spheres only, after the other two")
+    finally:
+        gpu.set_option("walk_yield", -1)
+
+
 def test_leaf_wait_changes_no_bit(gpu, orc):
     """Option leaf_wait (rt_kernels.h closest_bvh2 / bvh2_slice): how many lanes of a wave must stand on an object before
     the wave tests objects.  A waiting lane does nothing, so every ray sees the same boxes, objects and t_max in the same
