@@ -171,6 +171,9 @@ int         mirt_device_count(void);
  *  "walk_yield"     near-first BVH walks in resumable slices: a wave leaves the walk loop once this many of its
  *                   lanes have finished, shades them and resumes the others (1..64); 0: every wave waits for its
  *                   longest walk; -1 (default): the library's choice, currently 56 for batches of 2 Mi paths or more, else 0.  Same image.
+ *  "lds_top"        sliced near-first walk: this many nodes of the top of the tree are read from LDS instead of memory
+ *                   (0..256; -1, default: 32 for trees of 65536 nodes and more, else 0).  Takes effect at the next
+ *                   mirt_upload_scene.  Same image.
  *  "leaf_wait"      near-first BVH walks: a lane that reaches an object waits until this many lanes of its wave wait
  *                   with it (or none has a node left) before the objects are tested, all in one pass (1..64, default 4).
  *                   Same image: a waiting lane does nothing in between.

@@ -79,6 +79,8 @@ struct mirt_ctx {
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
     uint32_t leaf_wait = MIRT_LEAF_WANT;   // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2)
+    int32_t lds_top = -1;                   // sliced near-first walk: top-of-tree nodes read from LDS (0..256; -1: 32 for trees of 65536 nodes and more, else 0);
+                                            // takes effect at the next mirt_upload_scene
     int32_t walk_yield = -1;                // near-first walks in slices that end when this many lanes of a wave have finished;
                                             // 0: off, -1 (default): 56 for batches of 2 Mi paths or more
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
@@ -195,6 +197,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "leaf_wait")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "leaf_wait out of range"); c->leaf_wait = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "lds_top")) { if (value < -1 || value > 256) return fail(c, MIRT_ERR_ARG, "lds_top out of range"); c->lds_top = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "walk_yield")) { if (value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "walk_yield out of range"); c->walk_yield = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
     if (!strcmp(name, "paths_per_lane")) { if (value != 1 && value != 2) return fail(c, MIRT_ERR_ARG, "paths_per_lane is 1 or 2"); c->paths_per_lane = (uint32_t)value; return MIRT_OK; }
@@ -353,7 +356,9 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     c->lds_bytes = used + d.lds_nodes * d.node_bytes;
     c->lds_stack_bytes = d.stack_lds * MIRT_BLOCK * 4u;
     c->sc2.node_bytes = (uint32_t)sizeof(Node2);
-    c->sc2.lds_nodes = 0;                                                          // the near-first walks read their nodes from memory (rt_kernels.h closest_bvh2)
+    // near-first walks read their nodes from memory, except the sliced walk of a large tree, which takes the top levels from LDS
+    // (k_trace_bvh<4, ...>, rt_kernels.h bvh2_slice<.., LTOP>): option lds_top, -1 = 32 nodes for trees of 65536 nodes and more
+    c->sc2.lds_nodes = std::min<uint32_t>(c->lds_top >= 0 ? (uint32_t)c->lds_top : (c->sc2.n_nodes >= 65536u ? 32u : 0u), c->sc2.n_nodes);
     c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
     c->have_scene = true;
     return MIRT_OK;
@@ -438,7 +443,8 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
         if (mode == 0) { if (pl) { if (tex) { CALL(0, true, true); } else { CALL(0, true, false); } } else { if (tex) { CALL(0, false, true); } else { CALL(0, false, false); } } }      \
         else if (mode == 1) { if (pl) { if (tex) { CALL(1, true, true); } else { CALL(1, true, false); } } else { if (tex) { CALL(1, false, true); } else { CALL(1, false, false); } } } \
         else if (mode == 2) { if (pl) { if (tex) { CALL(2, true, true); } else { CALL(2, true, false); } } else { if (tex) { CALL(2, false, true); } else { CALL(2, false, false); } } } \
-        else { if (pl) { if (tex) { CALL(3, true, true); } else { CALL(3, true, false); } } else { if (tex) { CALL(3, false, true); } else { CALL(3, false, false); } } }                \
+        else if (mode == 3) { if (pl) { if (tex) { CALL(3, true, true); } else { CALL(3, true, false); } } else { if (tex) { CALL(3, false, true); } else { CALL(3, false, false); } } } \
+        else { if (pl) { if (tex) { CALL(4, true, true); } else { CALL(4, true, false); } } else { if (tex) { CALL(4, false, true); } else { CALL(4, false, false); } } }                \
     } while (0)
 
 static uint32_t trace_lds(const mirt_ctx *c, int mode)
@@ -488,7 +494,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     // one (its state costs 3-4 dwords of scratch) the slices pay from ~4 M paths on (485 spheres 1200x800@500 +13 %, 1 M spheres
     // 1920x1080@128 +10 %; 52/56/60/62 lanes: within 1 % / best / -1 % / -7 %); launches of ~1 M paths and fewer are 4 % faster plain
     const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : ((c->walk_yield < 0 && cap >= (2ull << 20)) ? 56u : 0u);
-    if (mode == 2 && yield_want) mode = 3;                  // the near-first walk in resumable slices (k_trace_bvh<3, ...>)
+    if (mode == 2 && yield_want) mode = c->sc2.lds_nodes ? 4 : 3;   // the near-first walk in resumable slices (k_trace_bvh<3, ...>; <4, ...>: top of the tree from LDS)
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
     const size_t capq = (size_t)npix_b * S;

@@ -364,6 +364,7 @@ template <class T> __device__ __forceinline__ T sgpr_pin(T x) { asm volatile("" 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) f32x4_t *GlobalF4;
+typedef const __attribute__((address_space(3))) f32x4_t *LdsF4;
 typedef const __attribute__((address_space(1))) u32x2_t *GlobalU2;
 
 // An object's primitive tested from a BVH leaf.  Left to itself the compiler sinks every field's load into the branch that uses it
@@ -479,7 +480,11 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
 // LDS/HBM slots indexed by lane, so it survives between slices by itself.  Per-path arithmetic is unchanged.
 struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
 
-template <bool PLDS>
+// LTOP (ACCEL 4): the first SceneDev::lds_nodes nodes (breadth-first numbering: the top levels) are read from the workgroup's LDS
+// copy under an explicit per-lane branch -- ds_read, not a flat load, so those steps make no L1 access at all.  Pays where the walk
+// waits on memory (1 M spheres +3.5 % with 32 nodes; 8/16/64: +1.5/+2.5/+2 %, 128 and more lose to the LDS they take); the branch
+// costs the 485-sphere walk, which is issue-bound, 1-2 %, hence a variant of its own.
+template <bool PLDS, bool LTOP>
 __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, uint32_t want, uint32_t leaf_want)
 {
     // a lane takes part while w.cur != MIRT_CHILD_NONE (closest_bvh2's end mark); lanes that hold no walk enter with the mark
@@ -492,13 +497,15 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
     const float4 *const sph4 = sgpr_pin(sc.sph4);
+    const uint32_t lds_n = LTOP ? sgpr_pin(sc.lds_nodes) : 0u;
     leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
     const unsigned long long entered = wave_mask(cur != MIRT_CHILD_NONE);
     for (;;) {
         if (cur >= 0) {
             Node2 n;
-            const GlobalF4 g = (GlobalF4)(nodes2 + cur);
-            const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
+            f32x4_t a, b, c, e;
+            if (LTOP && (uint32_t)cur < lds_n) { const LdsF4 l = (LdsF4)v.nodes + 4 * cur; a = l[0]; b = l[1]; c = l[2]; e = l[3]; }   // the top of the tree: LDS reads, not L1 accesses
+            else { const GlobalF4 g = (GlobalF4)(nodes2 + cur); a = g[0]; b = g[1]; c = g[2]; e = g[3]; }
             n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
             n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
             n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
@@ -1101,13 +1108,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         const MatRec *M;
         if constexpr (ACCEL != 0) { h.pos = o; h.nrm = d; h.mat = 0; M = a.sc.mats; radiance = mk(0.0f, 0.0f, 0.0f); }   // under the 64-register cap of the BVH kernels defined values allocate better (fewer spills)
         bool ready = live;                      // lanes whose closest hit is known in this iteration
-        if constexpr (ACCEL == 3) {
+        if constexpr (ACCEL >= 3) {
             if (live) {
                 if (ws.cur == MIRT_CHILD_NONE) {                                   // a new ray: start its walk (a walk under way keeps its state)
                     ws.cur = a.sc.root; ws.best = -1; ws.t_max = 3.402823466e+38f; ws.sp = 0;
                     ws.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
                 }
-                bvh2_slice<PLDS>(a.sc, lv, o, d, 0.001f, ws, a.slice_want, a.leaf_want);
+                bvh2_slice<PLDS, ACCEL == 4>(a.sc, lv, o, d, 0.001f, ws, a.slice_want, a.leaf_want);
             }
             ready = live && ws.cur == MIRT_CHILD_NONE;
         }
@@ -1115,7 +1122,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
             int32_t best;
-            if constexpr (ACCEL == 3) { best = ws.best; t_max = ws.t_max; }
+            if constexpr (ACCEL >= 3) { best = ws.best; t_max = ws.t_max; }
             else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max, a.leaf_want)
                       : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
@@ -1574,7 +1581,7 @@ __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST2_WAVES) k_trace2(TraceAr
 template <bool PLDS, bool TEX>
 __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
 template <int ACCEL, bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK, ACCEL == 3 ? MIRT_YIELD_WAVES : MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
+__global__ void __launch_bounds__(MIRT_BLOCK, ACCEL >= 3 ? MIRT_YIELD_WAVES : MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).

@@ -346,8 +346,16 @@ def test_sphere_leaf_records_follow_the_scene(gpu, orc):
         with pytest.raises(capi.MirtError):                                # wherever the sphere records are used
             gpu.upload_scene(s3)
         check(scene.spheres_world(w / h)[0], "spheres only, after the other two")
+        # the sliced walk with the top of the tree in LDS (k_trace_bvh<4, ...>, option lds_top; by default only trees of 65536 nodes
+        # and more): the same image whatever part of the tree the LDS copy holds, down to "all of it"
+        for top in (1, 7, 32, 256):
+            gpu.set_option("lds_top", top)
+            check(scene.spheres_world(w / h)[0], f"lds_top={top}")
+            check(s2, f"one rect among the spheres, lds_top={top}")
+        with pytest.raises(capi.MirtError):
+            gpu.set_option("lds_top", 257)
     finally:
-        gpu.set_option("walk_yield", -1)
+        gpu.set_option("walk_yield", -1); gpu.set_option("lds_top", -1)
 
 
 def test_leaf_wait_changes_no_bit(gpu, orc):
