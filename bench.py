@@ -257,7 +257,7 @@ def rooflines(args, st, sc, list_walk, bound, ext_ms, ext_launches, n_inst, work
         k_flop = rays * flop_per_ray + samples * FLOP_PER_SAMPLE_FIXED
         k_bytes = samples * RAD_BYTES                          # the only per-path HBM traffic: one radiance slot
     else:
-        kname = "k_trace<true,false>" if list_walk else "k_trace_bvh<3,false,false>"   # 3: the near-first walk in resumable slices, the default from 2 Mi paths per batch
+        kname = "k_trace<true,false>" if list_walk else ("k_trace_bvh<4,false,false>" if sc.n_objects > 65536 else "k_trace_bvh<3,false,false>")   # the near-first walk in resumable slices (the default from 2 Mi paths per batch); 4: top of the tree from LDS (trees of 65536 nodes and more)
         if work is None:                                       # no oracle counters in this run (--no-cpu-baseline or N > 1): the committed ones
             work = committed_work(args.workload)
             note = "boxes/spheres per ray from profiles/r02_work_counters.json (no CPU sample in this run)"
