@@ -121,8 +121,13 @@ struct Stack {                       // one lane's traversal stack (see SceneDev
     }
     __device__ __forceinline__ int32_t pop()
     {
+        // two address spaces spelled out: the plain conditional compiles to ONE flat load of a selected address, and a flat load
+        // goes through the texture addresser even when it ends in LDS
         --sp;
-        return sp < n_lds ? lds[sp * MIRT_BLOCK] : hbm[(size_t)(sp - n_lds) * stride];
+        int32_t x;
+        if (sp < n_lds) x = ((const __attribute__((address_space(3))) int32_t *)lds)[sp * MIRT_BLOCK];
+        else x = ((const __attribute__((address_space(1))) int32_t *)hbm)[(size_t)(sp - n_lds) * stride];
+        return x;
     }
 };
 __device__ __forceinline__ LdsView lds_view(const SceneDev &sc, unsigned char *base)
