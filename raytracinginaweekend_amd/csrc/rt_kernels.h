@@ -1143,7 +1143,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     // PLDS launches have the whole material table in LDS as well (mirt.hip): a plain LDS pointer, not a
                     // per-lane choice between two address spaces (flat loads and 64-bit address arithmetic)
                     if constexpr (PLDS) M = (const MatRec *)((const unsigned char *)lv.mats + __umul24((uint32_t)h.mat, (uint32_t)sizeof(MatRec)));
-                    else M = ((uint32_t)h.mat < a.sc.lds_mats) ? (const MatRec *)(lv.mats + h.mat) : (a.sc.mats + h.mat);
+                    else M = a.sc.mats + h.mat;                    // always from memory here: a per-lane choice of address space would make every
+                                                                   // material read a flat load (the texture addresser's work even when it ends in LDS)
                     need = scatter_need(M->kind, d, h.nrm, true);
                 }
             }
