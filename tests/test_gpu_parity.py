@@ -358,6 +358,29 @@ def test_sphere_leaf_records_follow_the_scene(gpu, orc):
         gpu.set_option("walk_yield", -1); gpu.set_option("lds_top", -1)
 
 
+def test_large_tree_variants_agree(gpu):
+    """A tree of more than 65536 nodes (90 000 spheres) switches the sliced walk to its variant with the top 32 nodes in LDS
+    (k_trace_bvh<4, ...>).  The persistent engine as it chooses, sliced, plain, and the wavefront engine render the same bits
+    and count the same rays."""
+    w, h = 256, 144
+    s, cam = scene.spheres_world(w / h, grid=150, look_from=(26.0, 6.0, 6.0))
+    assert s.n_prims > 65537
+    gpu.upload_scene(s); gpu.set_camera(cam)
+    try:
+        ref = None
+        for label, opts in (("default", {"engine": 1, "walk_yield": -1}), ("sliced", {"walk_yield": 56}), ("plain", {"walk_yield": 0}),
+                            ("wavefront", {"engine": 0})):
+            for k, v in opts.items():
+                gpu.set_option(k, v)
+            g = gpu.render(w, h, 8, 50, 7, capi.FLAG_ACCEL_AUTO, want=("sum",))
+            cur = (np.asarray(g["sum"]).copy(), g["stats"].rays)
+            ref = cur if ref is None else ref
+            H.assert_bits(cur[0], ref[0], f"90 000 spheres, {label}")
+            assert cur[1] == ref[1]
+    finally:
+        gpu.set_option("engine", 1); gpu.set_option("walk_yield", -1)
+
+
 def test_leaf_wait_changes_no_bit(gpu, orc):
     """Option leaf_wait (rt_kernels.h closest_bvh2 / bvh2_slice): how many lanes of a wave must stand on an object before
     the wave tests objects.  A waiting lane does nothing, so every ray sees the same boxes, objects and t_max in the same
