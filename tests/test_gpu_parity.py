@@ -358,23 +358,24 @@ def test_sphere_leaf_records_follow_the_scene(gpu, orc):
         gpu.set_option("walk_yield", -1); gpu.set_option("lds_top", -1)
 
 
-def test_large_tree_variants_agree(gpu):
+def test_large_tree_variants_agree(gpu, orc):
     """A tree of more than 65536 nodes (90 000 spheres) switches the sliced walk to its variant with the top 32 nodes in LDS
-    (k_trace_bvh<4, ...>).  The persistent engine as it chooses, sliced, plain, and the wavefront engine render the same bits
-    and count the same rays."""
+    (k_trace_bvh<4, ...>).  The persistent engine as it chooses, sliced, plain, and the wavefront engine render the bits of the
+    oracle walking the same tree near-first, and count the same rays."""
     w, h = 256, 144
     s, cam = scene.spheres_world(w / h, grid=150, look_from=(26.0, 6.0, 6.0))
     assert s.n_prims > 65537
+    capi.build_bvh(s)
     gpu.upload_scene(s); gpu.set_camera(cam)
+    osum, ost = orc.trace(s, cam, w, h, 8, 50, 7, orc.FLAG_ACCEL_ORDERED)
     try:
-        ref = None
+        ref = (osum, ost.rays)
         for label, opts in (("default", {"engine": 1, "walk_yield": -1}), ("sliced", {"walk_yield": 56}), ("plain", {"walk_yield": 0}),
                             ("wavefront", {"engine": 0})):
             for k, v in opts.items():
                 gpu.set_option(k, v)
             g = gpu.render(w, h, 8, 50, 7, capi.FLAG_ACCEL_AUTO, want=("sum",))
             cur = (np.asarray(g["sum"]).copy(), g["stats"].rays)
-            ref = cur if ref is None else ref
             H.assert_bits(cur[0], ref[0], f"90 000 spheres, {label}")
             assert cur[1] == ref[1]
     finally:
