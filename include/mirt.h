@@ -157,6 +157,11 @@ int         mirt_create(int device_id, mirt_ctx **out);
 void        mirt_destroy(mirt_ctx *ctx);                 /* HomemadeRayTracer::OnDestroy      */
 const char *mirt_last_error(const mirt_ctx *ctx);        /* ctx may be NULL: last create error */
 int         mirt_device_count(void);
+/* Versions of the HIP runtime and driver this library is bound to in this process (hipRuntimeGetVersion /
+ * hipDriverGetVersion; either pointer may be NULL).  No reference counterpart; hosts that hand the library device
+ * pointers and streams made by another HIP user in the same process (bench.py: torch) record it beside the path of
+ * the one libamdhip64 mapped. */
+int         mirt_runtime_version(int *hip_runtime, int *hip_driver);
 /* option names:
  *  "max_paths"      paths per batch (default 1 Gi; buffers are sized by the render at hand, up to this)
  *  "time_launches"  0/1: bracket every tracing-kernel launch with HIP events, sums reported in mirt_stats

@@ -92,7 +92,7 @@ HIT_DTYPE = np.dtype([("t", "<f4"), ("pos", "<f4", 3), ("nrm", "<f4", 3), ("u", 
 
 EXPORTS = [
     "mirt_abi_version", "mirt_check_abi",
-    "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_set_option",
+    "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_device_count", "mirt_runtime_version", "mirt_set_option",
     "mirt_upload_scene", "mirt_build_bvh", "mirt_set_camera", "mirt_render_device", "mirt_render_device_noalloc", "mirt_resolve_device", "mirt_render", "mirt_render_progressive",
     "mirt_aabb_hit_batch", "mirt_prim_hit_batch", "mirt_world_hit_batch", "mirt_scatter_batch",
     "mirt_multi_create", "mirt_multi_destroy", "mirt_multi_last_error", "mirt_multi_device_count", "mirt_multi_set_option",
@@ -124,6 +124,7 @@ def load():
     lib.mirt_destroy.argtypes = [vp]; lib.mirt_destroy.restype = None
     lib.mirt_last_error.argtypes = [vp]; lib.mirt_last_error.restype = C.c_char_p
     lib.mirt_device_count.argtypes = []
+    lib.mirt_runtime_version.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.mirt_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.mirt_upload_scene.argtypes = [vp, C.POINTER(SceneStruct)]
     lib.mirt_set_camera.argtypes = [vp, C.POINTER(CameraStruct)]
@@ -160,7 +161,45 @@ def load():
     if lib.mirt_check_abi(ABI_VERSION, C.sizeof(SceneStruct), C.sizeof(CameraStruct), HIT_DTYPE.itemsize, C.sizeof(RenderParams), C.sizeof(Stats)) != 0:
         raise MirtError("capi.py and libmirt.so disagree about the ABI: " + lib.mirt_last_error(None).decode())
     _lib = lib
+    check_single_hip_runtime()
     return lib
+
+
+def mapped_hip_runtimes(maps_text=None):
+    """The distinct libamdhip64 files mapped into this process (real paths), from /proc/self/maps."""
+    if maps_text is None:
+        with open("/proc/self/maps") as f:
+            maps_text = f.read()
+    seen = []
+    for line in maps_text.splitlines():
+        parts = line.split(None, 5)
+        if len(parts) == 6 and os.path.basename(parts[5]).startswith("libamdhip64.so"):
+            p = os.path.realpath(parts[5].removesuffix(" (deleted)"))
+            if p not in seen:
+                seen.append(p)
+    return seen
+
+
+def check_single_hip_runtime(maps_text=None):
+    """libmirt.so is linked against /opt/rocm's libamdhip64.so.7; torch bundles a libamdhip64.so of its own.  Device pointers
+    and stream handles cross between the two users (bench.py hands torch's to libmirt), which is sound only when both
+    resolved to ONE mapped runtime: the loader shares a library by SONAME when torch is imported FIRST (or not at all);
+    with libmirt loaded first, torch's loader finds its own copy by path and the process holds two runtimes, each with its
+    own device state.  Raises MirtError in that case; returns the one mapped path (None: none mapped yet)."""
+    rts = mapped_hip_runtimes(maps_text)
+    if len(rts) > 1:
+        raise MirtError("two HIP runtimes are mapped into this process: " + ", ".join(rts) + " -- import torch BEFORE "
+                        "raytracinginaweekend_amd.capi.load() (the loader then shares torch's libamdhip64 by SONAME), or do not import torch")
+    return rts[0] if rts else None
+
+
+def hip_runtime_info():
+    """{"path": the one libamdhip64 mapped, "hip_runtime": hipRuntimeGetVersion, "hip_driver": hipDriverGetVersion} as libmirt sees them."""
+    lib = load()
+    rt, drv = C.c_int(), C.c_int()
+    if lib.mirt_runtime_version(C.byref(rt), C.byref(drv)) != 0:
+        raise MirtError("mirt_runtime_version failed: " + lib.mirt_last_error(None).decode())
+    return {"path": check_single_hip_runtime(), "hip_runtime": rt.value, "hip_driver": drv.value}
 
 
 def _ptr(a):
@@ -177,6 +216,7 @@ class Context:
 
     def __init__(self, device=0):
         self.lib = load()
+        check_single_hip_runtime()                     # torch imported after load() would have brought a second one
         h = C.c_void_p()
         rc = self.lib.mirt_create(int(device), C.byref(h))
         if rc != 0:

@@ -110,6 +110,16 @@ extern "C" int mirt_device_count(void)
     return n;
 }
 
+extern "C" int mirt_runtime_version(int *hip_runtime, int *hip_driver)
+{
+    int rt = 0, drv = 0;
+    if (hipRuntimeGetVersion(&rt) != hipSuccess) { g_create_error = "hipRuntimeGetVersion failed"; return MIRT_ERR_HIP; }
+    if (hipDriverGetVersion(&drv) != hipSuccess) drv = 0;      // no driver in a container without a GPU: not an error here
+    if (hip_runtime) *hip_runtime = rt;
+    if (hip_driver) *hip_driver = drv;
+    return MIRT_OK;
+}
+
 extern "C" uint32_t mirt_abi_version(void) { return MIRT_ABI_VERSION; }
 
 extern "C" int mirt_check_abi(uint32_t version, size_t sizeof_scene, size_t sizeof_camera, size_t sizeof_hit, size_t sizeof_render_params, size_t sizeof_stats)
@@ -172,7 +182,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_sph4, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -333,7 +343,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         if (c->d_sph4.ensure(sph.size() * sizeof(float4))) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
         HIPCHK(c, hipMemcpy(c->d_sph4.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
         d.sph4 = (const float4 *)c->d_sph4.p;
-    }
+    } else c->d_sph4.release();                                   // a scene that cannot use the records does not keep the last one's
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
     d.root = tree.root;
     for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];

@@ -30,8 +30,8 @@ def test_golden_prim_hits(gpu):
         wn, p = key.rsplit("_", 2)[0], int(key.rsplit("_", 2)[1])
         s, _ = world(wn)
         gpu.upload_scene(s)
-        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, FLT_MAX), g[key], key)
-        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, 4.0), g[key + "4"], key + "4")
+        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, FLT_MAX), g[key], key, scene=s)
+        H.assert_hits_equal(gpu.prim_hit_batch(p, g[f"{wn}_{p}_org"], g[f"{wn}_{p}_dir"], 0.001, 4.0), g[key + "4"], key + "4", scene=s)
     assert np.array_equal(gpu.aabb_hit_batch(g["aabb_min"], g["aabb_max"], g["aabb_org"], g["aabb_dir"], 0.001, FLT_MAX), g["aabb_hit"])
     assert np.array_equal(gpu.aabb_hit_batch(g["aabb_min"], g["aabb_max"], g["aabb_org"], g["aabb_dir"], 0.001, 3.0), g["aabb_hit3"])
 
@@ -42,8 +42,8 @@ def test_golden_world_hits(gpu):
         s, _ = world(wn)
         s.set_bvh(g[f"{wn}_node_min"], g[f"{wn}_node_max"], g[f"{wn}_left"], g[f"{wn}_right"], int(g[f"{wn}_root"]))
         gpu.upload_scene(s)
-        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, 0), g[f"{wn}_bvh"], wn + " bvh")
-        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), g[f"{wn}_list"], wn + " list")
+        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, 0), g[f"{wn}_bvh"], wn + " bvh", scene=s)
+        H.assert_hits_equal(gpu.world_hit_batch(g[f"{wn}_org"], g[f"{wn}_dir"], 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), g[f"{wn}_list"], wn + " list", scene=s)
 
 
 def test_golden_scatter_and_camera(gpu):

@@ -135,7 +135,7 @@ def test_prim_hit(gpu, orc, world):
         for (t0, t1) in ((0.001, FLT_MAX), (0.001, 4.0)):
             g = gpu.prim_hit_batch(p, org, d, t0, t1); o = orc.prim_hit_batch(s, p, org, d, t0, t1)
             assert (o["prim"] >= 0).sum() > 100
-            H.assert_hits_equal(g, o, f"{world} prim {p}")
+            H.assert_hits_equal(g, o, f"{world} prim {p}", scene=s)
 
 
 @pytest.mark.parametrize("world", ["cornell", "two_boxes", "spheres4", "spheres"])
@@ -151,7 +151,7 @@ def test_world_hit(gpu, orc, world):
     for flags in (0, capi.FLAG_ACCEL_LIST):
         g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags); o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
         assert (o["prim"] >= 0).sum() > 1000
-        H.assert_hits_equal(g, o, f"{world} flags={flags}")
+        H.assert_hits_equal(g, o, f"{world} flags={flags}", scene=s)
     # the library's own BVH (no tree passed): same closest hits as the list
     s.nodes = None
     gpu.upload_scene(s)
@@ -402,7 +402,7 @@ def test_leaf_wait_changes_no_bit(gpu, orc):
                 g = gpu.render(w, h, 5, 50, 9, capi.FLAG_ACCEL_ORDERED)
                 H.assert_bits(g["sum"], osum, f"leaf_wait={lw} walk_yield={wy}")
                 assert g["stats"].rays == ost.rays
-        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED), o_hits, "hit batch, ordered walk")
+        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED), o_hits, "hit batch, ordered walk", scene=s)
         with pytest.raises(capi.MirtError):
             gpu.set_option("leaf_wait", 0)
     finally:
@@ -465,7 +465,7 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     # the oracle's restatement of the near-first walk on the library's own tree: whole records, tie winners included
     capi.build_bvh(s)
     o2, st2 = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, orc.FLAG_ACCEL_ORDERED)
-    H.assert_hits_equal(g, o2, "ordered walk vs its restatement")
+    H.assert_hits_equal(g, o2, "ordered walk vs its restatement", scene=s)
     a = gpu.render(w, h, 3, 50, 7, capi.FLAG_ACCEL_ORDERED)
     osum, st3 = orc.trace(s, cam, w, h, 3, 50, 7, orc.FLAG_ACCEL_ORDERED)
     H.assert_bits(a["sum"], osum, "ordered image vs ordered oracle")
@@ -476,7 +476,7 @@ def test_ordered_traversal_and_own_bvh(gpu, orc, world):
     gpu.upload_scene(s)
     g1 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0)
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
-    H.assert_hits_equal(g1, o1, "own tree, reference order")
+    H.assert_hits_equal(g1, o1, "own tree, reference order", scene=s)
 
 
 @pytest.mark.parametrize("world", ["cornell", "spheres4", "spheres"])
@@ -500,18 +500,18 @@ def test_axis_parallel_rays(gpu, orc, world):
     d[::7] = np.where(d[::7] == 0, np.float32(-0.0), d[::7])       # both signs of zero
     o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
     assert (o["prim"] >= 0).sum() > 250
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list")
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, "axis-parallel list", scene=s)
     # the reference's BVH walk culls a ray that only grazes a node box (AABB.cpp:17 uses <=), so it misses some
     # edge and corner hits the list finds; the device does the same in the same cases
     o1, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order")
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o1, "axis-parallel reference order", scene=s)
     # near-first: the whole hit record equals the oracle's walk of the same tree in the same order.  Against the
     # reference-order walk the closest t is the same except on grazing rays: the reference's walk, having met the floor
     # first, culls the box of a ball that touches the floor there (AABB.cpp:17, `<=`) and so misses the ball's hit an ulp
     # nearer; the near-first walk meets the ball first and agrees with the list.  A few rays of this lattice in 16 384.
     g = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
     o2, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
-    H.assert_hits_equal(g, o2, "axis-parallel near-first")
+    H.assert_hits_equal(g, o2, "axis-parallel near-first", scene=s)
     assert np.array_equal(g["prim"] >= 0, o1["prim"] >= 0)
     differs = g["t"].view(np.uint32) != o1["t"].view(np.uint32)
     assert differs.sum() <= 8 and np.array_equal(g["t"].view(np.uint32)[differs], o["t"].view(np.uint32)[differs]) and (g["t"][differs] < o1["t"][differs]).all()
@@ -530,7 +530,7 @@ def test_million_spheres(gpu, orc):
     d[:, 1] = -np.abs(d[:, 1])                                  # look down at the field
     o, st = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, 0)
     assert (o["prim"] > 3).sum() > 200                           # small spheres are being hit, not just the ground
-    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o, "1M ref order")
+    H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, 0), o, "1M ref order", scene=s)
     g2 = gpu.world_hit_batch(org, d, 0.001, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
     H.assert_bits(g2["t"], o["t"], "1M near-first t"); assert np.array_equal(g2["prim"], o["prim"])
     w, h = 96, 64
@@ -706,7 +706,7 @@ def test_random_scenes(gpu, orc, seed):
     for flags in (0, capi.FLAG_ACCEL_LIST):
         o, _ = orc.world_hit_batch(s, org, d, 0.001, FLT_MAX, flags)
         assert (o["prim"] >= 0).sum() > 250
-        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags), o, f"seed {seed} flags {flags}")
+        H.assert_hits_equal(gpu.world_hit_batch(org, d, 0.001, FLT_MAX, flags), o, f"seed {seed} flags {flags}", scene=s)
     w, h = 72, 48
     for flags in (0, capi.FLAG_ACCEL_LIST):
         g = gpu.render(w, h, 4, 50, seed, flags)

@@ -83,10 +83,88 @@ def test_bench_launcher_starts_one_fresh_process_per_rank(tmp_path):
     assert sharding.launch_local_ranks(2, [sys.executable, str(script), str(out), "1"], timeout=120) == 7
 
 
+CHILD2 = r"""
+import os, sys, time
+rank = int(os.environ["RANK"])
+sys.stderr.write(f"rank {rank} attempt {os.environ['MIRT_LAUNCH_ATTEMPT']} legacy={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')} nccl_debug={os.environ.get('NCCL_DEBUG')}\n")
+mode = sys.argv[1]
+if mode == "hang":
+    time.sleep(600)
+if mode == "die-early" and os.environ["MIRT_LAUNCH_ATTEMPT"] == "1" and rank == 1:
+    sys.stderr.write("hipIpcGetMemHandle: invalid argument (simulated)\n"); sys.exit(9)
+if mode == "die-early" and os.environ["MIRT_LAUNCH_ATTEMPT"] == "1":
+    time.sleep(600)                                # the surviving rank waits in the rendezvous; the launcher stops it
+sys.path.insert(0, sys.argv[3])
+from raytracinginaweekend_amd import sharding
+sharding.passed_first_barrier()
+if mode == "die-late" and rank == 0:
+    sys.exit(5)
+if rank == 0:
+    open(sys.argv[2], "a").write(os.environ["MIRT_LAUNCH_ATTEMPT"] + ":" + str(os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")) + " ")
+    print('{"line": "json"}')
+"""
+
+
+def test_launcher_timeout_logs_and_one_fresh_retry(tmp_path, capfd):
+    """the launcher has a timeout, keeps each rank's stderr in bench_rank<r>.err and prints the failing
+    rank's tail; ranks that die before their first barrier get ONE more set of fresh processes with HSA_ENABLE_IPC_MODE_LEGACY
+    unset and NCCL_DEBUG=WARN; ranks that die later, or hang, do not."""
+    from raytracinginaweekend_amd import sharding
+    script = tmp_path / "child2.py"; script.write_text(CHILD2)
+    out = tmp_path / "out.txt"
+    logs = tmp_path / "logs"
+    env = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_DEBUG")}
+
+    def run(mode, **kw):
+        return sharding.launch_local_ranks(2, [sys.executable, str(script), mode, str(out), ROOT], env=env, log_dir=str(logs), **kw)
+
+    assert sharding.DEFAULT_LAUNCH_TIMEOUT == 900.0
+    import inspect
+    assert inspect.signature(sharding.launch_local_ranks).parameters["timeout"].default == 900.0      # no caller waits for ever by default
+    assert run("ok") == 0 and out.read_text() == "1:0 "
+    assert "attempt 1 legacy=0 nccl_debug=None" in (logs / "bench_rank1.err").read_text()
+    o, e = capfd.readouterr()
+    assert '{"line": "json"}' in o and '"line"' not in e                        # rank 0's stdout stays clean of the ranks' stderr
+    out.write_text("")
+    assert run("die-early") == 0 and out.read_text() == "2:None "              # second set: the variable unset, NCCL_DEBUG=WARN
+    assert "attempt 2 legacy=None nccl_debug=WARN" in (logs / "bench_rank0.err").read_text()
+    o, e = capfd.readouterr()
+    assert "rank 1 ended with status 9" in e and "hipIpcGetMemHandle" in e and "one more set of fresh processes" in e
+    out.write_text("")
+    assert run("die-late") == 5 and out.read_text() == ""                      # the process group had come up: no retry
+    t0 = __import__("time").monotonic()
+    assert run("hang", timeout=1.5) == 124 and __import__("time").monotonic() - t0 < 30
+    assert "no result after" in capfd.readouterr()[1]
+    assert not list(logs.glob("*.ready"))
+
+
+def test_two_hip_runtimes_are_refused():
+    """libmirt.so and torch must share ONE mapped libamdhip64; the check reads /proc/self/maps."""
+    from raytracinginaweekend_amd import capi
+    one = "7f00-7f01 r-xp 00000000 00:00 1    /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.0\n7f01-7f02 rw-p 00001000 00:00 1    /opt/rocm-7.2.0/lib/libamdhip64.so.7.2.0\n"
+    two = one + "7f03-7f04 r-xp 00000000 00:00 2    /usr/lib/python3/dist-packages/torch/lib/libamdhip64.so\n"
+    assert capi.mapped_hip_runtimes("7f00-7f01 r-xp 00000000 00:00 0 \n") == []
+    assert len(capi.mapped_hip_runtimes(one)) == 1 and capi.check_single_hip_runtime(one).endswith("libamdhip64.so.7.2.0")
+    with pytest.raises(capi.MirtError, match="two HIP runtimes"):
+        capi.check_single_hip_runtime(two)
+    # fresh processes: libmirt.so alone, and after torch -> exactly one runtime; torch AFTER libmirt -> two, refused
+    import subprocess
+    def run(code):
+        return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % ROOT + code], capture_output=True, text=True, timeout=300)
+    r = run("from raytracinginaweekend_amd import capi\ni = capi.hip_runtime_info()\nprint(i['path'], i['hip_runtime'])")
+    assert r.returncode == 0 and "libamdhip64" in r.stdout and int(r.stdout.split()[-1]) > 0, r.stderr
+    r = run("import torch\nfrom raytracinginaweekend_amd import capi\nprint(capi.hip_runtime_info()['path'])")
+    assert r.returncode == 0 and "torch" in r.stdout, r.stderr              # torch first: libmirt binds to the runtime torch mapped
+    r = run("from raytracinginaweekend_amd import capi\ncapi.load()\nimport torch\ncapi.hip_runtime_info()")
+    assert r.returncode != 0 and "two HIP runtimes are mapped" in r.stderr  # the order the check exists for
+
+
 def test_bench_cli_shape():
     """bench.py's launcher branch is taken before torch or a GPU is touched, and every BASELINE config has a workload."""
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index("launch_local_ranks(args.gpus") < src.index("import torch")
+    assert src.index("import torch  ") < src.index("capi.hip_runtime_info()") < src.index("torch.cuda.set_device")     # torch first, the check before any GPU work
+    assert "--launch-timeout" in src and '"launch_attempts"' in src and '"hip_runtime"' in src
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
