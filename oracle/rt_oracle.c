@@ -654,15 +654,6 @@ static box_t object_box(const orc_scene *sc, uint32_t obj)
  * AABB.cpp:17; an object's box -- the reference never box-tests an object -- only on t_max < t_min.  The root's own box is
  * not tested.  Object boxes come from g_ordered_obox, set by the entry points below for the duration of a call. */
 static const box_t *g_ordered_obox;
-/* Leaf groups (round 3, NOT in the reference; the library's rule, rt_kernels.h bvh2_slice / mirt.hip "leaf groups"): in a scene
- * whose objects are all single spheres, a node over at most g_leaf_group (4) objects is a LEAF of the near-first walk.  When
- * the walk reaches it, its objects are tested one after the other in the subtree's left-to-right order -- t_max shrinking and
- * `<=` letting a later one win a tie, like a HitableCombo (Hitables.cpp:130-142) -- and none of the boxes inside it is tested.
- * Its own box is tested in its parent like an object's (grazing interval passes).  g_ordered_cnt[node] = objects below the
- * node (0: the scene does not qualify), set with the object boxes by the entry points below. */
-static const uint32_t *g_ordered_cnt;
-static uint32_t g_leaf_group = 4;
-void orc_set_leaf_group(uint32_t k) { g_leaf_group = k ? k : 1; }          /* 1: every object a leaf of its own (round 2's walk) */
 static int slab_ordered(box_t b, const ray_t *r, v3 invd, float t_min, float t_max, int is_object, float *t_near)
 {
     for (unsigned a = 0; a < 3; ++a) {
@@ -682,28 +673,18 @@ static box_t ordered_child_box(const orc_scene *sc, int32_t c)
     box_t b = { ld3(sc->node_min + 3 * (size_t)c), ld3(sc->node_max + 3 * (size_t)c) };
     return b;
 }
-static int ordered_is_leaf(int32_t c) { return c < 0 || (g_ordered_cnt && g_ordered_cnt[c] <= g_leaf_group); }
-/* the objects of a leaf group, left to right */
-static int ordered_group_hit(const orc_scene *sc, int32_t c, const ray_t *r, float t_min, float *t_max, hit_t *rec, orc_stats *st)
-{
-    if (c == ORC_CHILD_NONE) return 0;
-    if (c < 0) return object_hit(sc, (uint32_t)~c, r, t_min, t_max, rec, st);
-    int any = ordered_group_hit(sc, sc->node_left[c], r, t_min, t_max, rec, st);
-    any |= ordered_group_hit(sc, sc->node_right[c], r, t_min, t_max, rec, st);
-    return any;
-}
 static int bvh_hit_ordered(const orc_scene *sc, const ray_t *r, float t_min, float *t_max, hit_t *rec, orc_stats *st)
 {
     int32_t stack[128]; int sp = 0, any = 0;
     int32_t cur = sc->root;
     const v3 invd = V(1.0f / r->dir.x, 1.0f / r->dir.y, 1.0f / r->dir.z);
     for (;;) {
-        if (cur >= 0 && !ordered_is_leaf(cur)) {
+        if (cur >= 0) {
             const int32_t l = sc->node_left[cur], rr = sc->node_right[cur];
             float tl = 0.0f, tr = 0.0f;
             int hl = 0, hr = 0;
-            if (l != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hl = slab_ordered(ordered_child_box(sc, l), r, invd, t_min, *t_max, ordered_is_leaf(l), &tl); }
-            if (rr != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hr = slab_ordered(ordered_child_box(sc, rr), r, invd, t_min, *t_max, ordered_is_leaf(rr), &tr); }
+            if (l != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hl = slab_ordered(ordered_child_box(sc, l), r, invd, t_min, *t_max, l < 0, &tl); }
+            if (rr != ORC_CHILD_NONE) { if (st) st->nodes_visited++; hr = slab_ordered(ordered_child_box(sc, rr), r, invd, t_min, *t_max, rr < 0, &tr); }
             if (hl && hr) {
                 const int left_first = tl <= tr;
                 if (sp < 128) stack[sp++] = left_first ? rr : l;
@@ -713,18 +694,12 @@ static int bvh_hit_ordered(const orc_scene *sc, const ray_t *r, float t_min, flo
             if (hl) { cur = l; continue; }
             if (hr) { cur = rr; continue; }
         } else if (cur != ORC_CHILD_NONE) {
-            any |= ordered_group_hit(sc, cur, r, t_min, t_max, rec, st);
+            any |= object_hit(sc, (uint32_t)~cur, r, t_min, t_max, rec, st);
         }
         if (sp == 0) break;
         cur = stack[--sp];
     }
     return any;
-}
-static uint32_t ordered_count(const orc_scene *sc, int32_t c, uint32_t *cnt)
-{
-    if (c == ORC_CHILD_NONE) return 0;
-    if (c < 0) return 1;
-    return cnt[c] = ordered_count(sc, sc->node_left[c], cnt) + ordered_count(sc, sc->node_right[c], cnt);
 }
 static box_t *ordered_begin(const orc_scene *sc, uint32_t flags)
 {
@@ -732,18 +707,9 @@ static box_t *ordered_begin(const orc_scene *sc, uint32_t flags)
     box_t *b = (box_t *)malloc((sc->n_objects ? sc->n_objects : 1) * sizeof *b);
     for (uint32_t o = 0; b && o < sc->n_objects; ++o) b[o] = object_box(sc, o);
     g_ordered_obox = b;
-    /* leaf groups only where the library forms them: every object one sphere, object i = primitive i */
-    int qualifies = sc->n_prims == sc->n_objects && sc->n_nodes > 0 && g_leaf_group > 1;
-    for (uint32_t o = 0; qualifies && o < sc->n_objects; ++o)
-        qualifies = sc->obj_count[o] == 1 && sc->obj_first[o] == o && sc->prim_kind[o] == ORC_PRIM_SPHERE;
-    g_ordered_cnt = NULL;
-    if (qualifies) {
-        uint32_t *cnt = (uint32_t *)calloc(sc->n_nodes, sizeof *cnt);
-        if (cnt) { ordered_count(sc, sc->root, cnt); g_ordered_cnt = cnt; }
-    }
     return b;
 }
-static void ordered_end(box_t *b) { if (b) { g_ordered_obox = NULL; free(b); free((void *)g_ordered_cnt); g_ordered_cnt = NULL; } }
+static void ordered_end(box_t *b) { if (b) { g_ordered_obox = NULL; free(b); } }
 
 void orc_object_bounds(const orc_scene *sc, float *bmin, float *bmax)
 {

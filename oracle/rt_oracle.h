@@ -127,8 +127,6 @@ void orc_aabb_hit_batch(const float *bmin, const float *bmax, size_t nbox,
 /* one primitive through its whole instance chain (Hitables.cpp:163-173,241-264,13-54,93-115) */
 void orc_prim_hit_batch(const orc_scene *sc, uint32_t prim, const float *org, const float *dir,
                         size_t nray, float t_min, float t_max, orc_hit *out);
-/* test infrastructure: size of the leaf groups of the ORDERED walk (default 4, the library's; 1 = none, round 2's walk) */
-void orc_set_leaf_group(uint32_t k);
 /* closest hit in the world: BVH (SimpleObject.cpp:389-406) or list (flags & ORC_FLAG_ACCEL_LIST) */
 void orc_world_hit_batch(const orc_scene *sc, const float *org, const float *dir, size_t nray,
                          float t_min, float t_max, uint32_t flags, orc_hit *out, orc_stats *st);

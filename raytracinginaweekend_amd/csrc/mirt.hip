@@ -66,7 +66,7 @@ struct mirt_ctx {
     mirt_camera cam{};
     DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_mdq, d_rdy;            // MIRT_DEFER_MD builds: per-wave queues of the second (metal/dielectric) stream
-    DevBuf d_sph4, d_sph_obj;       // SceneDev::sph4, sph_obj
+    DevBuf d_sph4;                  // SceneDev::sph4
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -182,7 +182,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_sph4, &c->d_sph_obj, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_sph4, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -275,6 +275,17 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         for (int a = 0; a < 3; ++a) { nodes[i].mn[a] = tree.box[i].mn[a]; nodes[i].mx[a] = tree.box[i].mx[a]; }
         nodes[i].left = tree.left[i]; nodes[i].right = tree.right[i];
     }
+    std::vector<Node2> nodes2(tree.box.size());
+    for (size_t i = 0; i < nodes2.size(); ++i) {
+        Node2 &n = nodes2[i]; memset(&n, 0, sizeof n);
+        n.left = tree.left[i]; n.right = tree.right[i];
+        auto child_box = [&](int32_t ch) -> host::Box {
+            if (ch == MIRT_CHILD_NONE) { host::Box e; for (int a = 0; a < 3; ++a) { e.mn[a] = 3.402823466e+38f; e.mx[a] = -3.402823466e+38f; } return e; }
+            return ch < 0 ? tree.obox[~ch] : tree.box[ch];
+        };
+        host::Box l = child_box(n.left), r = child_box(n.right);
+        for (int a = 0; a < 3; ++a) { n.lmn[a] = l.mn[a]; n.lmx[a] = l.mx[a]; n.rmn[a] = r.mn[a]; n.rmx[a] = r.mx[a]; }
+    }
     std::vector<uint2> objs(s->n_objects);
     bool single = true;
     for (uint32_t o = 0; o < s->n_objects; ++o) { objs[o] = make_uint2(s->obj_first[o], s->obj_count[o]); single &= s->obj_count[o] == 1; }
@@ -286,62 +297,6 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         r.inv_ior = 1.0f / r.ior;
         r.r0 = schlick_r0(r.ior);                       // same IEEE divide and multiply as in the kernel (no contraction on either side)
         for (int i = 0; i < 3; ++i) { r.albedo[i] = s->mat_albedo[3 * (size_t)m + i]; r.emit[i] = s->mat_emit[3 * (size_t)m + i]; }
-    }
-    // ---- the near-first walk's tree (Node2: both children's boxes in the parent) and, for scenes of spheres, its leaf groups
-    // Scenes whose objects are all single spheres get (centre, r*r) per object as 16 bytes -- all a leaf test reads (rt_kernels.h
-    // sphere_leaf_t) -- and LEAF GROUPS: a node over at most four objects becomes a leaf of the near-first walk, its objects laid
-    // out as consecutive records in the subtree's left-to-right order and tested in a tight loop, no box inside it is visited.
-    // One node step (four 16-byte accesses per lane, two slab tests) buys at most two sphere tests at the bottom of the tree;
-    // a group buys up to four for one access each.  The oracle's ordered walk follows the same rule (oracle/rt_oracle.c
-    // ordered_is_leaf), so hit records incl. tie winners stay bit-exact.  Leaf code: ~(first << 2 | count - 1).
-    bool all_spheres = single && s->n_prims == s->n_objects && s->n_prims > 0 && s->n_prims < (1u << 29);
-    for (uint32_t p = 0; all_spheres && p < s->n_prims; ++p) all_spheres = prims[p].info == 0u && objs[p].x == p;
-    std::vector<float4> sph; std::vector<uint32_t> sph_obj;
-    std::vector<Node2> nodes2;
-    int32_t root2 = tree.root;
-    {
-        const size_t nn = tree.box.size();
-        std::vector<uint32_t> cnt(all_spheres ? nn : 0);
-        if (all_spheres) for (size_t i = nn; i-- > 0;) {             // breadth-first numbering: children have larger indices
-            auto below = [&](int32_t ch) -> uint32_t { return ch == MIRT_CHILD_NONE ? 0u : (ch < 0 ? 1u : cnt[ch]); };
-            cnt[i] = below(tree.left[i]) + below(tree.right[i]);
-        }
-        auto is_group = [&](int32_t ch) { return all_spheres && ch != MIRT_CHILD_NONE && (ch < 0 || cnt[ch] <= 4u); };
-        std::vector<int32_t> stack;
-        auto emit_group = [&](int32_t ch) -> int32_t {             // the subtree's objects, left to right
-            const uint32_t first = (uint32_t)sph.size();
-            stack.assign(1, ch);
-            while (!stack.empty()) {
-                const int32_t x = stack.back(); stack.pop_back();
-                if (x == MIRT_CHILD_NONE) continue;
-                if (x < 0) { const uint32_t p = (uint32_t)~x; sph.push_back(make_float4(prims[p].off[0], prims[p].off[1], prims[p].off[2], prims[p].ga[2])); sph_obj.push_back(p); }
-                else { stack.push_back(tree.right[x]); stack.push_back(tree.left[x]); }
-            }
-            return ~(int32_t)((first << 2) | ((uint32_t)sph.size() - first - 1u));
-        };
-        // kept nodes renumbered breadth-first again (index < K = the top levels, what lds_top stages)
-        std::vector<int32_t> order, newid(nn, -1);
-        if (is_group(tree.root)) root2 = emit_group(tree.root);
-        else { order.push_back(tree.root); newid[tree.root] = 0; }
-        for (size_t h = 0; h < order.size(); ++h) {
-            const int32_t ch[2] = { tree.left[order[h]], tree.right[order[h]] };
-            for (int k = 0; k < 2; ++k) if (ch[k] >= 0 && !is_group(ch[k])) { newid[ch[k]] = (int32_t)order.size(); order.push_back(ch[k]); }
-        }
-        nodes2.resize(order.size());
-        for (size_t i = 0; i < order.size(); ++i) {
-            Node2 &n = nodes2[i]; memset(&n, 0, sizeof n);
-            const int32_t ch[2] = { tree.left[order[i]], tree.right[order[i]] };
-            int32_t code[2];
-            host::Box bx[2];
-            for (int k = 0; k < 2; ++k) {
-                if (ch[k] == MIRT_CHILD_NONE) { code[k] = MIRT_CHILD_NONE; for (int a = 0; a < 3; ++a) { bx[k].mn[a] = 3.402823466e+38f; bx[k].mx[a] = -3.402823466e+38f; } continue; }
-                bx[k] = ch[k] < 0 ? tree.obox[~ch[k]] : tree.box[ch[k]];
-                code[k] = is_group(ch[k]) ? emit_group(ch[k]) : (ch[k] < 0 ? ch[k] : newid[ch[k]]);
-            }
-            n.left = code[0]; n.right = code[1];
-            for (int a = 0; a < 3; ++a) { n.lmn[a] = bx[0].mn[a]; n.lmx[a] = bx[0].mx[a]; n.rmn[a] = bx[1].mn[a]; n.rmx[a] = bx[1].mx[a]; }
-        }
-        if (nodes2.empty()) nodes2.resize(1);                       // a scene that is one leaf group: nothing to walk, the buffer just exists
     }
     if (c->d_prims.ensure(prims.size() * sizeof(PrimRec)) || c->d_lprims.ensure(lprims.size() * sizeof(PrimRec)) || c->d_nodes.ensure(nodes.size() * sizeof(NodeRec)) ||
         c->d_nodes2.ensure(nodes2.size() * sizeof(Node2)) ||
@@ -378,15 +333,19 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;
-    d.sph4 = nullptr; d.sph_obj = nullptr;
+    // scenes whose objects are all single unrotated spheres: the 16 bytes a leaf test reads, per object (rt_kernels.h sphere_leaf_t)
+    d.sph4 = nullptr;
+    bool all_spheres = single && s->n_prims == s->n_objects && s->n_prims > 0;
+    for (uint32_t p = 0; all_spheres && p < s->n_prims; ++p) all_spheres = prims[p].info == 0u && objs[p].x == p;
     if (all_spheres) {
-        if (c->d_sph4.ensure(sph.size() * sizeof(float4)) || c->d_sph_obj.ensure(sph_obj.size() * sizeof(uint32_t))) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
+        std::vector<float4> sph(s->n_prims);
+        for (uint32_t p = 0; p < s->n_prims; ++p) sph[p] = make_float4(prims[p].off[0], prims[p].off[1], prims[p].off[2], prims[p].ga[2]);
+        if (c->d_sph4.ensure(sph.size() * sizeof(float4))) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
         HIPCHK(c, hipMemcpy(c->d_sph4.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_sph_obj.p, sph_obj.data(), sph_obj.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        d.sph4 = (const float4 *)c->d_sph4.p; d.sph_obj = (const uint32_t *)c->d_sph_obj.p;
-    } else { c->d_sph4.release(); c->d_sph_obj.release(); }   // a scene that cannot use the records does not keep the last one's
+        d.sph4 = (const float4 *)c->d_sph4.p;
+    } else c->d_sph4.release();                                   // a scene that cannot use the records does not keep the last one's
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
-    d.root = tree.root;                                          // c->sc2.root: the near-first tree's, below
+    d.root = tree.root;
     for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];
     // LDS plan: the short part of the traversal stack, the material table, small primitive tables, and whatever
     // is left of the budget for the top of the tree.  Occupancy beats LDS-resident nodes (measured: 1M spheres,
@@ -409,8 +368,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     c->sc2.node_bytes = (uint32_t)sizeof(Node2);
     // near-first walks read their nodes from memory, except the sliced walk of a large tree, which takes the top levels from LDS
     // (k_trace_bvh<4, ...>, rt_kernels.h bvh2_slice<.., LTOP>): option lds_top, -1 = 32 nodes for trees of 65536 nodes and more
-    c->sc2.lds_nodes = std::min<uint32_t>(c->lds_top >= 0 ? (uint32_t)c->lds_top : (c->sc2.n_nodes >= 65536u ? 32u : 0u), (uint32_t)nodes2.size());
-    c->sc2.root = root2;                                          // a node of nodes2, or a leaf group when the whole scene is one
+    c->sc2.lds_nodes = std::min<uint32_t>(c->lds_top >= 0 ? (uint32_t)c->lds_top : (c->sc2.n_nodes >= 65536u ? 32u : 0u), c->sc2.n_nodes);
     c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
     c->have_scene = true;
     return MIRT_OK;

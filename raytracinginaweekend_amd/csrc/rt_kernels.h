@@ -57,10 +57,7 @@ struct SceneDev {
     const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
     uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
     uint32_t single;                              // every object is one primitive: object index == primitive index
-    const float4  *sph4;                          // scenes of single spheres only (else NULL): (centre, r*r) per object -- all a leaf test reads, in ONE 16-byte
-                                                  // access -- ordered by LEAF GROUP: the near-first tree (nodes2) of such a scene has the nodes over at most four
-                                                  // objects collapsed into leaves ~(first << 2 | count - 1) that name runs of this array (mirt.hip "leaf groups")
-    const uint32_t *sph_obj;                      // sph4 position -> the scene's primitive index
+    const float4  *sph4;                          // scenes of single unrotated spheres only (else NULL): (centre, r*r) per object -- all a leaf test reads, in ONE 16-byte access
     const uint2   *objs;   uint32_t n_objects;   // (first, count)
     const MatRec  *mats;   uint32_t n_mats;
     int32_t root;
@@ -454,15 +451,70 @@ __device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3
 // LDS write, the stack's two newest entries fetched at the head of every pass so that pops are selects: bit-identical, SALU
 // -9 %, lane use 54.5 -> 59.8 %, but VALU +10 % because every lane now pays for every case in every pass, and the walk is
 // bound by VALU issue: 6-12 % SLOWER.  SALU instructions issue beside other waves' VALU work, so the branches this form
-// removes cost little.  Numbers in profiles/r03_trace_ablation.txt; this is round 2's form.)
-struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
-// What a near-first walk reports as its winner: in a scene of spheres the position in the group-ordered copy (SceneDev::sph4),
-// which sph_obj maps back to the scene's own primitive index; else the primitive index itself.
-__device__ __forceinline__ int32_t walk_winner(const SceneDev &sc, int32_t best)
+// removes cost little.  Leaf groups -- a node over at most four spheres collapsed into one leaf, its spheres consecutive 16-byte
+// records tested in a loop -- were built too, with the oracle's twin: 11 % fewer node steps per ray but 1.8x the sphere tests, and
+// those run in the leaf passes, where few lanes take part: 5 % slower on 485 spheres, 1.5 % on 1 M.  Numbers in
+// profiles/r03_trace_ablation.txt; this is round 2's form.)
+template <bool PLDS>
+__device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max, uint32_t leaf_want)
 {
-    if (sc.sph4 && best >= 0) best = (int32_t)((const __attribute__((address_space(1))) uint32_t *)sc.sph_obj)[best];
+    int32_t best = -1;
+    Stack stk(sc, v);
+    // A finished walk is cur == MIRT_CHILD_NONE (the root of an empty tree already is): the three questions the loop asks the
+    // wave -- who stands on a node, who on an object, who is still walking -- are then one compare of `cur` each, and a
+    // ballot of a plain compare is that compare (a ballot of a flag carried around the loop costs a select and a compare more).
+    int32_t cur = sc.root;
+    const Prims<PLDS> P(sc, v);
+    const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
+    const uint2 *const objs = sgpr_pin(sc.objs);
+    const uint32_t single = sgpr_pin(sc.single);
+    const float4 *const sph4 = sgpr_pin(sc.sph4);
+    leaf_want = sgpr_pin(leaf_want);
+    const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
+    for (;;) {
+        if (cur >= 0) {
+            Node2 n;                                                      // always from memory: staging the top levels in LDS measured neutral, and the
+            const GlobalF4 g = (GlobalF4)(nodes2 + cur);                  // per-lane choice between two address spaces costs flat loads
+            const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
+            n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
+            n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
+            n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
+            float tl = 0.0f, tr = 0.0f;
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, n.left, tl);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, n.right, tr);
+            if (hl && hr) {
+                const bool left_first = tl <= tr;
+                stk.push(left_first ? n.right : n.left);
+                cur = left_first ? n.left : n.right;
+            } else if (hl) cur = n.left;
+            else if (hr) cur = n.right;
+            else if (stk.sp == 0) cur = MIRT_CHILD_NONE;
+            else cur = stk.pop();
+        }
+        const bool at_leaf = (uint32_t)cur > (uint32_t)MIRT_CHILD_NONE;  // negative and not the end mark: ~object
+        const unsigned long long lm = wave_mask(at_leaf);
+        if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
+            if (at_leaf) {
+                if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
+                    float t;
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, t_max, t)) { t_max = t; best = ~cur; }
+                } else {
+                    uint32_t first = (uint32_t)~cur, cnt = 1;
+                    if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        float t;
+                        if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                    }
+                }
+                if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
+            }
+        }
+        if (wave_mask(cur != MIRT_CHILD_NONE) == 0ull) break;
+    }
     return best;
 }
+
+struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
 
 // LTOP (ACCEL 4): the first SceneDev::lds_nodes nodes (breadth-first numbering: the top levels) are read from the workgroup's LDS
 // copy under an explicit per-lane branch -- ds_read, not a flat load, so those steps make no L1 access at all.  Pays where the walk
@@ -510,14 +562,9 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
         const unsigned long long lm = wave_mask(at_leaf);
         if (lm != 0ull && ((uint32_t)__popcll(lm) >= leaf_want || wave_mask(cur >= 0) == 0ull)) {
             if (at_leaf) {
-                if (sph4) {                                               // wave-uniform: every object is one sphere, leaves are groups of up to four
-                    // leaf code ~(first << 2 | count - 1): `count` consecutive records of the group-ordered copy, tested in that
-                    // order with t_max shrinking and `<=` letting a later one win a tie (Hitables.cpp:130-142, the oracle's twin)
-                    const uint32_t ref = (uint32_t)~cur, first = ref >> 2, last = first + (ref & 3u);
-                    for (uint32_t i = first; i <= last; ++i) {
-                        float t;
-                        if (sphere_leaf_t(sph4, i, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)i; }
-                    }
+                if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
+                    float t;
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = ~cur; }
                 } else {
                     uint32_t first = (uint32_t)~cur, cnt = 1;
                     if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
@@ -533,18 +580,6 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
         if (still == 0ull || (uint32_t)__popcll(entered & ~still) >= want) break;
     }
     w.cur = cur; w.sp = stk.sp;
-}
-
-// The plain walk (ACCEL 2): one slice that never yields (no wave has 65 lanes to finish).
-template <bool PLDS>
-__device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max, uint32_t leaf_want)
-{
-    WalkState w;
-    w.cur = sc.root; w.best = -1; w.t_max = t_max; w.sp = 0;
-    w.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                      // AABB.cpp:9
-    bvh2_slice<PLDS, false>(sc, v, o, d, t_min, w, 65u, leaf_want);
-    t_max = w.t_max;
-    return walk_winner(sc, w.best);
 }
 
 // Path ids enumerate pixels tile by tile (8x8) rather than row by row, so the 64 camera rays a wave generates at
@@ -1123,7 +1158,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             float t_max = 3.402823466e+38f;   // FLT_MAX
             const float t_min = 0.001f;
             int32_t best;
-            if constexpr (ACCEL >= 3) { best = walk_winner(a.sc, ws.best); t_max = ws.t_max; }
+            if constexpr (ACCEL >= 3) { best = ws.best; t_max = ws.t_max; }
             else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max, a.leaf_want)
                       : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186

@@ -56,7 +56,6 @@ def lib():
         L.orc_resolve.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]; L.orc_resolve.restype = None
         L.orc_write_ppm.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp]; L.orc_write_ppm.restype = C.c_int
         L.orc_max_threads.argtypes = []; L.orc_max_threads.restype = C.c_int
-        L.orc_set_leaf_group.argtypes = [C.c_uint32]; L.orc_set_leaf_group.restype = None
         _lib = L
     return _lib
 
@@ -178,11 +177,6 @@ def resolve(sum_rgb, spp_total, flags=0):
 def write_ppm(path, rgba8):
     rgba8 = np.ascontiguousarray(rgba8, np.uint8); h, w = rgba8.shape[:2]
     return lib().orc_write_ppm(os.fsencode(path), w, h, _p(rgba8))
-
-
-def set_leaf_group(k):
-    """Size of the leaf groups of the ORDERED walk (4 = the library's rule; 1 = none, round 2's walk)."""
-    lib().orc_set_leaf_group(int(k))
 
 
 def max_threads():
