@@ -305,7 +305,15 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     HIPCHK(c, hipMemcpy(c->d_prims.p, prims.data(), prims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_lprims.p, lprims.data(), lprims.size() * sizeof(PrimRec), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_nodes.p, nodes.data(), nodes.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+#if MIRT_NODE_SOA
+    {   // measurement build: the same records as sixteen planes of one dword per node
+        std::vector<uint32_t> planes(nodes2.size() * 16);
+        for (size_t i = 0; i < nodes2.size(); ++i) for (size_t k = 0; k < 16; ++k) planes[k * nodes2.size() + i] = ((const uint32_t *)&nodes2[i])[k];
+        HIPCHK(c, hipMemcpy(c->d_nodes2.p, planes.data(), planes.size() * 4, hipMemcpyHostToDevice));
+    }
+#else
     HIPCHK(c, hipMemcpy(c->d_nodes2.p, nodes2.data(), nodes2.size() * sizeof(Node2), hipMemcpyHostToDevice));
+#endif
     HIPCHK(c, hipMemcpy(c->d_objs.p, objs.data(), objs.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_mats.p, mats.data(), mats.size() * sizeof(MatRec), hipMemcpyHostToDevice));
 
@@ -369,6 +377,9 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     // near-first walks read their nodes from memory, except the sliced walk of a large tree, which takes the top levels from LDS
     // (k_trace_bvh<4, ...>, rt_kernels.h bvh2_slice<.., LTOP>): option lds_top, -1 = 32 nodes for trees of 65536 nodes and more
     c->sc2.lds_nodes = std::min<uint32_t>(c->lds_top >= 0 ? (uint32_t)c->lds_top : (c->sc2.n_nodes >= 65536u ? 32u : 0u), c->sc2.n_nodes);
+#if MIRT_NODE_SOA
+    c->sc2.lds_nodes = 0;                                           // measurement build: the planes are not records, nothing to stage
+#endif
     c->lds_bytes2 = used + c->sc2.lds_nodes * c->sc2.node_bytes;
     c->have_scene = true;
     return MIRT_OK;

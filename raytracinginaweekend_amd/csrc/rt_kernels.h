@@ -431,6 +431,28 @@ __device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3
     return prim_t(pr, o, d, t_min, t_max, t);
 }
 
+// MIRT_NODE_SOA (measurement only, tools: profiles/r03_trace_ablation.txt): the near-first walk's nodes as sixteen planes of
+// one dword per node ("coalesced SoA node fetches", north_star kernel item 2) instead of one 64-byte record.  A wave's lanes
+// stand on unrelated nodes, so a plane read coalesces nothing: it is sixteen 4-byte accesses per lane where the record is four
+// of 16 bytes.  Same tree, same arithmetic, same image.
+#ifndef MIRT_NODE_SOA
+#define MIRT_NODE_SOA 0
+#endif
+__device__ __forceinline__ void fetch_node2(const Node2 *nodes2, uint32_t n_nodes, int32_t cur, f32x4_t &a, f32x4_t &b, f32x4_t &c, f32x4_t &e)
+{
+#if MIRT_NODE_SOA
+    const __attribute__((address_space(1))) float *pl = (const __attribute__((address_space(1))) float *)nodes2 + cur;
+    const size_t n = n_nodes;
+    a.x = pl[0]; a.y = pl[n]; a.z = pl[2 * n]; a.w = pl[3 * n];
+    b.x = pl[4 * n]; b.y = pl[5 * n]; b.z = pl[6 * n]; b.w = pl[7 * n];
+    c.x = pl[8 * n]; c.y = pl[9 * n]; c.z = pl[10 * n]; c.w = pl[11 * n];
+    e.x = pl[12 * n]; e.y = pl[13 * n]; e.z = pl[14 * n]; e.w = pl[15 * n];
+#else
+    const GlobalF4 g = (GlobalF4)(nodes2 + cur);
+    a = g[0]; b = g[1]; c = g[2]; e = g[3];
+#endif
+}
+
 // Near-first traversal of the same tree (ACCEL 2, 3, 4).  A node carries both children's boxes; each is tested
 // with AABB::Hit's arithmetic (AABB.cpp:5-21; 1/dir is hoisted, it does not depend on the box) against the
 // current t_max, the nearer child (larger-or-equal entry t goes on the stack) is visited first so t_max
@@ -466,6 +488,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     int32_t cur = sc.root;
     const Prims<PLDS> P(sc, v);
     const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
+    const uint32_t n_nodes = MIRT_NODE_SOA ? sgpr_pin(sc.n_nodes) : 0u;
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
     const float4 *const sph4 = sgpr_pin(sc.sph4);
@@ -474,8 +497,8 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     for (;;) {
         if (cur >= 0) {
             Node2 n;                                                      // always from memory: staging the top levels in LDS measured neutral, and the
-            const GlobalF4 g = (GlobalF4)(nodes2 + cur);                  // per-lane choice between two address spaces costs flat loads
-            const f32x4_t a = g[0], b = g[1], c = g[2], e = g[3];
+            f32x4_t a, b, c, e;                                           // per-lane choice between two address spaces costs flat loads
+            fetch_node2(nodes2, n_nodes, cur, a, b, c, e);
             n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
             n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
             n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
@@ -530,6 +553,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const Prims<PLDS> P(sc, v);
     const f3 invd = w.invd;
     const Node2 *const nodes2 = sgpr_pin(sc.nodes2);
+    const uint32_t n_nodes = MIRT_NODE_SOA ? sgpr_pin(sc.n_nodes) : 0u;
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
     const float4 *const sph4 = sgpr_pin(sc.sph4);
@@ -541,7 +565,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
             Node2 n;
             f32x4_t a, b, c, e;
             if (LTOP && (uint32_t)cur < lds_n) { const LdsF4 l = (LdsF4)v.nodes + 4 * cur; a = l[0]; b = l[1]; c = l[2]; e = l[3]; }   // the top of the tree: LDS reads, not L1 accesses
-            else { const GlobalF4 g = (GlobalF4)(nodes2 + cur); a = g[0]; b = g[1]; c = g[2]; e = g[3]; }
+            else fetch_node2(nodes2, n_nodes, cur, a, b, c, e);
             n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
             n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
             n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
