@@ -80,7 +80,22 @@ typedef struct mirt_scene {
     const uint8_t  *tex_rgba8;   /* m_pixelData of all textures back to back: R,G,B,A per texel, row 0 = top
                                     (what tgaRead(.., TGA_READER_ABGR) returns, tga_reader.cpp) */
     const int32_t  *mat_texture; /* [n_mats] texture sampled for the albedo (Lambertian, Metal), -1 = mat_albedo */
+    /* General instance chains.  The reference's hitables compose freely (Hitables.h:20-106): SphereHitable has its own
+     * m_center (Hitables.cpp:20,37,65), TranslatedInstance / RotatedInstance nest in any order (Hitables.cpp:163-173,241-264)
+     * and HitableCombo holds any IHitable (Hitables.cpp:130-142).  A primitive in CHAIN FORM is one leaf with the list of the
+     * instances around it, outermost first; a combo distributes over its children, so an object is still a run of primitives,
+     * tested in order with t_max shrinking.  prim_chain may be NULL (n_ops 0): every primitive is then in the factory form above. */
+    const uint32_t *prim_chain;  /* [n_prims] 0 = factory form (prim_off, prim_rot, sphere centre 0); k > 0 = chain form, whose ops
+                                    are op_kind/op_arg[k-1 .. k-1+prim_nops[p]) and which ignores prim_off, prim_rot and the rotation
+                                    bit of prim_axes                                          */
+    const uint32_t *prim_nops;   /* [n_prims] instances around the leaf, 0..MIRT_MAX_CHAIN_OPS */
+    const float    *prim_center; /* [3 n_prims] SphereHitable::m_center of chain-form spheres  */
+    uint32_t        n_ops;
+    const uint32_t *op_kind;     /* [n_ops] MIRT_OP_*                                          */
+    const float    *op_arg;      /* [3 n_ops] translate: m_offset (Hitables.h:87); rotate: m_sinTheta, m_cosTheta (Hitables.h:97-98), 0 */
 } mirt_scene;
+#define MIRT_MAX_CHAIN_OPS 8u
+enum { MIRT_OP_TRANSLATE = 0, MIRT_OP_ROTATE_X = 1, MIRT_OP_ROTATE_Y = 2, MIRT_OP_ROTATE_Z = 3 };  /* 1 + RotatedInstance's rotateAxis */
 
 /* The SimpleCamera members GetRay reads (SimpleCamera.h:35-56, SimpleCamera.cpp:55-60). */
 typedef struct mirt_camera {
@@ -144,7 +159,7 @@ typedef struct mirt_ctx mirt_ctx;
  *    returns MIRT_ERR_ARG when it is not the size the library was built with (and writes nothing);
  *  - a host checks everything once at load: `if (MIRT_CHECK_ABI() != MIRT_OK) refuse to run`.
  * MIRT_ABI_VERSION is bumped whenever a struct, an enum value or a signature changes. */
-#define MIRT_ABI_VERSION 2u
+#define MIRT_ABI_VERSION 3u
 uint32_t mirt_abi_version(void);
 int      mirt_check_abi(uint32_t version, size_t sizeof_scene, size_t sizeof_camera, size_t sizeof_hit,
                         size_t sizeof_render_params, size_t sizeof_stats);

@@ -347,8 +347,43 @@ static void unpack_rect(const orc_scene *sc, uint32_t p, rect_t *q, int *has_rot
  *   sphere: TranslatedInstance(SphereHitable(0,r))                       SimpleObject.cpp:136
  *   rect  : TranslatedInstance(RotZ(RotY(RotX(AxisAlignedRectHitable)))) SimpleObject.cpp:173-181
  * Hit: Hitables.cpp:163-173 (translate) -> :241-264 (rotate, outermost = z) -> leaf.     */
+/* A primitive in chain form (include/mirt.h): the leaf with the instances around it, outermost first.  This is the reference's
+ * recursion written as a loop: every TranslatedInstance::Hit (Hitables.cpp:163-173) / RotatedInstance::Hit (:241-264) first
+ * transforms the ray and calls its child, and on a hit transforms the record on the way back out -- so the ray passes the ops
+ * outermost to innermost, the record innermost to outermost.  The sphere keeps its own centre (Hitables.cpp:20,37,65). */
+static v3 ld3(const float *p);
+static int chain_form(const orc_scene *sc, uint32_t p) { return sc->prim_chain && sc->prim_chain[p] != 0; }
+static int prim_hit_chain(const orc_scene *sc, uint32_t p, const ray_t *r, float t_min, float t_max, hit_t *rec)
+{
+    const uint32_t first = sc->prim_chain[p] - 1u, n = sc->prim_nops[p];
+    int mat = (int)sc->prim_mat[p];
+    ray_t cur = *r;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint32_t kind = sc->op_kind[first + k]; const float *a = sc->op_arg + 3 * (size_t)(first + k);
+        if (kind == 0) { ray_t moved = { v_sub(cur.org, V(a[0], a[1], a[2])), cur.dir }; cur = moved; }     /* :166 */
+        else cur = rot_ray_in(&cur, kind - 1u, a[0], a[1]);                                              /* :244-250 */
+    }
+    int hit;
+    if (sc->prim_kind[p] == ORC_PRIM_SPHERE)
+        hit = sphere_hit(ld3(sc->prim_center + 3 * (size_t)p), sc->prim_geom[5 * (size_t)p], mat, &cur, t_min, t_max, rec);
+    else {
+        rect_t q; int has_rot; unpack_rect(sc, p, &q, &has_rot);
+        hit = rect_hit(&q, mat, &cur, t_min, t_max, rec);
+    }
+    if (hit) {
+        for (uint32_t k = n; k-- > 0;) {
+            const uint32_t kind = sc->op_kind[first + k]; const float *a = sc->op_arg + 3 * (size_t)(first + k);
+            if (kind == 0) rec->pos = v_add(rec->pos, V(a[0], a[1], a[2]));                              /* :169 */
+            else rot_hit_out(rec, kind - 1u, a[0], a[1]);                                                /* :253-260 */
+        }
+        rec->prim = (int)p;
+    }
+    return hit;
+}
+
 static int prim_hit(const orc_scene *sc, uint32_t p, const ray_t *r, float t_min, float t_max, hit_t *rec)
 {
+    if (chain_form(sc, p)) return prim_hit_chain(sc, p, r, t_min, t_max, rec);
     v3 off = V(sc->prim_off[3 * p], sc->prim_off[3 * p + 1], sc->prim_off[3 * p + 2]);
     ray_t moved = { v_sub(r->org, off), r->dir };                          /* :166 */
     int mat = (int)sc->prim_mat[p];
@@ -619,9 +654,27 @@ static box_t rot_box(box_t in, unsigned rotAxis, float s, float c)         /* Hi
     box_t r = { mn, mx };
     return r;
 }
-static box_t object_box(const orc_scene *sc, uint32_t obj)
+/* A chain-form primitive's box: the leaf's, carried through its instances from the innermost out (Hitables.cpp:175-180, :208-238).
+ * For a sphere this is the box AROUND ITS CENTRE -- the reference's SphereHitable::BoundingBox (Hitables.cpp:56-60) forgets the
+ * centre, which is harmless for its factories (centre 0) and wrong for any other sphere; the boxes here are the library's own
+ * (its builder and the object boxes of the near-first walk), which must contain what they guard. */
+static box_t prim_box_chain(const orc_scene *sc, uint32_t p)
 {
-    uint32_t first = sc->obj_first[obj], cnt = sc->obj_count[obj];
+    box_t b;
+    if (sc->prim_kind[p] == ORC_PRIM_SPHERE) {
+        float r = sc->prim_geom[5 * (size_t)p]; v3 c = ld3(sc->prim_center + 3 * (size_t)p), rv = V(r, r, r);
+        b.mn = v_sub(c, rv); b.mx = v_add(c, rv);
+    } else { rect_t q; int hr; unpack_rect(sc, p, &q, &hr); b = rect_box(&q); }
+    const uint32_t first = sc->prim_chain[p] - 1u, n = sc->prim_nops[p];
+    for (uint32_t k = n; k-- > 0;) {
+        const uint32_t kind = sc->op_kind[first + k]; const float *a = sc->op_arg + 3 * (size_t)(first + k);
+        if (kind == 0) { v3 off = V(a[0], a[1], a[2]); b.mn = v_add(b.mn, off); b.mx = v_add(b.mx, off); }
+        else b = rot_box(b, kind - 1u, a[0], a[1]);
+    }
+    return b;
+}
+static box_t object_box_factory(const orc_scene *sc, uint32_t first, uint32_t cnt)
+{
     v3 off = ld3(sc->prim_off + 3 * (size_t)first);
     box_t b;
     if (sc->prim_kind[first] == ORC_PRIM_SPHERE) {                         /* Hitables.cpp:56-60 */
@@ -644,6 +697,20 @@ static box_t object_box(const orc_scene *sc, uint32_t obj)
         }
     }
     b.mn = v_add(b.mn, off); b.mx = v_add(b.mx, off);                      /* Hitables.cpp:175-180 */
+    return b;
+}
+/* An object of factory-form primitives is one of the factories' shapes (a sphere, a rect, a cube's six faces inside ONE chain):
+ * its box is built the way the reference builds it, combo first, then the chain.  An object with a chain-form primitive is a
+ * general combo: the union, in order, of its primitives' boxes (Hitables.cpp:152-161). */
+static box_t object_box(const orc_scene *sc, uint32_t obj)
+{
+    uint32_t first = sc->obj_first[obj], cnt = sc->obj_count[obj];
+    int any_chain = 0;
+    for (uint32_t i = 0; i < cnt; ++i) any_chain |= chain_form(sc, first + i);
+    if (!any_chain) return object_box_factory(sc, first, cnt);
+    box_t b = chain_form(sc, first) ? prim_box_chain(sc, first) : object_box_factory(sc, first, 1);
+    for (uint32_t i = 1; i < cnt; ++i)
+        b = box_combine(chain_form(sc, first + i) ? prim_box_chain(sc, first + i) : object_box_factory(sc, first + i, 1), b);
     return b;
 }
 /* NOT in the reference: the near-first walk the library runs under MIRT_FLAG_ACCEL_ORDERED / _AUTO (rt_kernels.h

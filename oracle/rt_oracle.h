@@ -75,6 +75,13 @@ typedef struct orc_scene {
     const uint32_t *tex_width, *tex_height, *tex_offset;   /* [n] size and first texel index            */
     const uint8_t  *tex_rgba8;   /* R,G,B,A per texel, row 0 = top                                     */
     const int32_t  *mat_texture; /* [n_mats] texture index or -1                                       */
+    /* general instance chains (include/mirt.h): chain-form primitives = a leaf + its instances, outermost first */
+    const uint32_t *prim_chain;  /* [n_prims] or NULL; 0 = factory form, k > 0 = ops [k-1, k-1+prim_nops[p])          */
+    const uint32_t *prim_nops;
+    const float    *prim_center; /* [3n] SphereHitable::m_center (chain form)                                          */
+    uint32_t        n_ops;
+    const uint32_t *op_kind;     /* 0 translate, 1..3 rotate about x, y, z                                             */
+    const float    *op_arg;      /* [3 n_ops] offset | sin, cos, 0                                                     */
 } orc_scene;
 
 typedef struct orc_camera {      /* SimpleCamera members used by GetRay, 19 floats */

@@ -14,6 +14,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libmirt.so")
 PRIM_SPHERE, PRIM_RECT = 0, 1
 MAT_DIFFUSE_LIGHT, MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC = 0, 1, 2, 3
 CHILD_NONE = -(1 << 31)
+OP_TRANSLATE, OP_ROTATE_X, OP_ROTATE_Y, OP_ROTATE_Z = 0, 1, 2, 3
+MAX_CHAIN_OPS = 8
 FLAG_ONE_SPP, FLAG_NORMAL_DISPLAY, FLAG_ACCEL_LIST, FLAG_ACCEL_AUTO, FLAG_ACCEL_ORDERED = 1, 2, 4, 16, 32
 
 f32p = C.POINTER(C.c_float)
@@ -38,6 +40,7 @@ class SceneStruct(C.Structure):
         ("node_right", i32p), ("root", C.c_int32), ("ambient", C.c_float * 3),
         ("n_textures", C.c_uint32), ("tex_width", u32p), ("tex_height", u32p), ("tex_offset", u32p),
         ("tex_rgba8", u8p), ("mat_texture", i32p),
+        ("prim_chain", u32p), ("prim_nops", u32p), ("prim_center", f32p), ("n_ops", C.c_uint32), ("op_kind", u32p), ("op_arg", f32p),
     ]
 
     def __init__(self, *a, **kw):
@@ -71,7 +74,7 @@ class Stats(C.Structure):
         self.struct_size = C.sizeof(Stats)
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MULTI_MAX_DEVICES = 16
 REDUCE_AUTO, REDUCE_PEER, REDUCE_RCCL = 0, 1, 2
 

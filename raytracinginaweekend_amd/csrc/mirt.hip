@@ -67,6 +67,8 @@ struct mirt_ctx {
     DevBuf d_prims, d_lprims, d_nodes, d_nodes2, d_objs, d_mats, d_texs, d_texels;
     DevBuf d_mdq, d_rdy;            // MIRT_DEFER_MD builds: per-wave queues of the second (metal/dielectric) stream
     DevBuf d_sph4;                  // SceneDev::sph4
+    DevBuf d_ops;                   // SceneDev::ops: the instances of chain-form primitives
+    bool has_chains = false;        // the scene holds chain-form primitives: the FULL kernel variants
     DevBuf d_spill;                 // traversal-stack levels beyond SceneDev::stack_lds, [level][thread of the grid]
     DevBuf d_prog_sum;              // mirt_render_progressive: the radiance sum kept between calls
     uint32_t prog_w = 0, prog_h = 0, prog_spp = 0;
@@ -182,7 +184,7 @@ extern "C" void mirt_destroy(mirt_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_sph4, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
+    DevBuf *bufs[] = { &c->d_prims, &c->d_lprims, &c->d_nodes, &c->d_nodes2, &c->d_objs, &c->d_mats, &c->d_texs, &c->d_texels, &c->d_sph4, &c->d_ops, &c->d_spill, &c->d_mdq, &c->d_rdy, &c->d_prog_sum, &c->d_queues, &c->d_rad, &c->d_counts, &c->d_len, &c->d_tmp_sum, &c->d_tmp_pix, &c->d_tmp_rgba };
     for (DevBuf *b : bufs) b->release();
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -233,13 +235,25 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     c->have_scene = false;
 
     std::vector<PrimRec> prims(s->n_prims);
+    bool has_chains = false;
     for (uint32_t p = 0; p < s->n_prims; ++p) {
         PrimRec &r = prims[p];
         memset(&r, 0, sizeof r);
         for (int i = 0; i < 3; ++i) r.off[i] = s->prim_off[3 * (size_t)p + i];
         const float *g = s->prim_geom + 5 * (size_t)p;
         r.mat = s->prim_mat[p];
-        if (s->prim_kind[p] == MIRT_PRIM_SPHERE) {
+        const bool chain = host::chain_form(*s, p);                        // a leaf with its own list of instances (rt_device.h OpRec)
+        if (chain) {
+            has_chains = true;
+            const bool sphere = s->prim_kind[p] == MIRT_PRIM_SPHERE;
+            for (int i = 0; i < 3; ++i) r.off[i] = sphere ? s->prim_center[3 * (size_t)p + i] : 0.0f;
+            const uint32_t ax = s->prim_axes[p];
+            r.info = (sphere ? 0u : (1u | ((ax & 3) << 1) | (((ax >> 2) & 3) << 3) | (((ax >> 4) & 3) << 5) | (((ax >> 6) & 1) << 7))) | (1u << 9) | (s->prim_nops[p] << 16);
+            if (sphere) { r.ga[0] = g[0]; r.ga[1] = 1.f / g[0]; r.ga[2] = g[0] * g[0]; }
+            else { r.ga[0] = g[0]; r.ga[1] = g[1]; r.ga[2] = g[2]; r.gb[0] = g[3]; r.gb[1] = g[4]; }
+            const uint32_t first = s->prim_chain[p] - 1u;
+            memcpy(&r.rot[0], &first, 4);
+        } else if (s->prim_kind[p] == MIRT_PRIM_SPHERE) {
             r.info = 0;
             r.ga[0] = g[0]; r.ga[1] = 1.f / g[0]; r.ga[2] = g[0] * g[0];   // Vec3.h:85-88, Hitables.cpp:23
         } else {
@@ -255,7 +269,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     // The list walk's copy: stable-sorted by class so that each class is one tight loop (rt_kernels.h closest_list);
     // .mat carries the primitive's own index, which is what acceptance and the caller need.
     auto list_class = [](const PrimRec &r) -> uint32_t {
-        if (PI_ROT(r.info)) return 4u;
+        if (PI_ROT(r.info) || PI_CHAIN(r.info)) return 4u;
         if (PI_KIND(r.info) == MIRT_PRIM_SPHERE) return 3u;
         const uint32_t a = PI_AAX(r.info), b = PI_BAX(r.info), cc = PI_CAX(r.info);
         if (a == 0 && b == 1 && cc == 2) return 0u;
@@ -352,6 +366,14 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         HIPCHK(c, hipMemcpy(c->d_sph4.p, sph.data(), sph.size() * sizeof(float4), hipMemcpyHostToDevice));
         d.sph4 = (const float4 *)c->d_sph4.p;
     } else c->d_sph4.release();                                   // a scene that cannot use the records does not keep the last one's
+    d.ops = nullptr; c->has_chains = has_chains;
+    if (has_chains && s->n_ops) {
+        std::vector<OpRec> ops(s->n_ops);
+        for (uint32_t k = 0; k < s->n_ops; ++k) ops[k] = OpRec{ s->op_kind[k], s->op_arg[3 * (size_t)k], s->op_arg[3 * (size_t)k + 1], s->op_arg[3 * (size_t)k + 2] };
+        if (c->d_ops.ensure(ops.size() * sizeof(OpRec))) return fail(c, MIRT_ERR_NOMEM, "mirt_upload_scene: hipMalloc failed");
+        HIPCHK(c, hipMemcpy(c->d_ops.p, ops.data(), ops.size() * sizeof(OpRec), hipMemcpyHostToDevice));
+        d.ops = (const OpRec *)c->d_ops.p;
+    }
     d.mats = (const MatRec *)c->d_mats.p; d.n_mats = s->n_mats;
     d.root = tree.root;
     for (int i = 0; i < 3; ++i) d.ambient[i] = s->ambient[i];
@@ -458,7 +480,7 @@ static uint32_t bounce_occupancy(const mirt_ctx *c, int mode)
     return (uint32_t)n;
 }
 
-// k_trace<PLDS, TEX> (list) or k_trace_bvh<ACCEL, PLDS, TEX> for this scene and mode
+// k_trace<PLDS, FULL> (list) or k_trace_bvh<ACCEL, PLDS, FULL> for this scene and mode (FULL: image textures and/or chain-form primitives)
 #define MIRT_TRACE_DISPATCH(mode, pl, tex, CALL)                                                                  \
     do {                                                                                                          \
         if (mode == 0) { if (pl) { if (tex) { CALL(0, true, true); } else { CALL(0, true, false); } } else { if (tex) { CALL(0, false, true); } else { CALL(0, false, false); } } }      \
@@ -473,11 +495,12 @@ static uint32_t trace_lds(const mirt_ctx *c, int mode)
     return mode >= 2 ? c->lds_bytes2 : (mode == 0 ? c->lds_bytes - c->lds_stack_bytes : c->lds_bytes);
 }
 // The list walk of a scene without image textures runs two paths per lane (k_trace2) when the paths_per_lane option says 2
-static bool two_paths(const mirt_ctx *c, int mode) { return mode == 0 && c->sc.n_textures == 0 && c->paths_per_lane == 2 && !MIRT_DEFER_MD; }
+static bool full_variant(const mirt_ctx *c) { return c->sc.n_textures != 0 || c->has_chains; }   // image textures and/or chain-form primitives
+static bool two_paths(const mirt_ctx *c, int mode) { return mode == 0 && !full_variant(c) && c->paths_per_lane == 2 && !MIRT_DEFER_MD; }
 static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32_t grid, hipStream_t st)
 {
     const uint32_t lds = trace_lds(c, mode);
-    const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
+    const bool pl = c->prims_in_lds, tex = full_variant(c);
     dim3 g(grid), b(MIRT_BLOCK);
     if (two_paths(c, mode)) { if (pl) hipLaunchKernelGGL((k_trace2<true>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace2<false>), g, b, lds, st, a); return; }
 #define MIRT_CALL(A, P, T) do { if (A == 0) hipLaunchKernelGGL((k_trace<P, T>), g, b, lds, st, a); else hipLaunchKernelGGL((k_trace_bvh<(A == 0 ? 1 : A), P, T>), g, b, lds, st, a); } while (0)
@@ -487,7 +510,7 @@ static void launch_trace(const mirt_ctx *c, int mode, const TraceArgs &a, uint32
 static uint32_t trace_occupancy(const mirt_ctx *c, int mode)
 {
     const uint32_t lds = trace_lds(c, mode);
-    const bool pl = c->prims_in_lds, tex = c->sc.n_textures != 0;
+    const bool pl = c->prims_in_lds, tex = full_variant(c);
     int n = 0;
     hipError_t e = hipSuccess;
     if (two_paths(c, mode)) {
@@ -552,7 +575,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     }
     HIPCHK(c, hipMemsetAsync(counts, 0, n_batches * per_batch * sizeof(uint32_t), st));
 #if MIRT_DEFER_MD
-    if (mode == 0 && c->sc.n_textures == 0) {                        // the second stream's per-wave queues (experimental build)
+    if (mode == 0 && !full_variant(c)) {                             // the second stream's per-wave queues (experimental build)
         if (fixed) return fail(c, MIRT_ERR_STATE, "mirt_render_device_noalloc: not available in a MIRT_DEFER_MD build");
         const size_t waves = (size_t)max_grid * (MIRT_BLOCK / 64);
         if (c->d_mdq.ensure(waves * MDQ_PLANES * MDQ_CAP * sizeof(float4)) || c->d_rdy.ensure(waves * RDY_PLANES * RDY_CAP * sizeof(float4)))
@@ -726,6 +749,7 @@ extern "C" int mirt_render_device(mirt_ctx *c, const mirt_render_params *p, floa
     const int mode = accel_mode(c, p->flags);
     if (c->engine == 1) return render_persistent(c, p, d_sum, st, stats, mode, spp_begin, spp_count, one_spp);
     if (c->sc.n_textures) return fail(c, MIRT_ERR_STATE, "mirt_render_device: the wavefront engine (option engine=0) renders single-colour scenes only; this scene has image textures");
+    if (c->has_chains) return fail(c, MIRT_ERR_STATE, "mirt_render_device: the wavefront engine (option engine=0) renders the factories' shapes only; this scene has primitives in chain form (general instance chains)");
 
     // batch geometry: npix_b pixels x S samples <= capacity (the queues cost 96 B per path: at most 256 Mi paths here)
     const uint64_t cap = std::min<uint64_t>(std::min<uint64_t>(c->max_paths, 256ull << 20), npix_total * spp_count);

@@ -224,6 +224,10 @@ struct PrimRec {            // 64 B; a sphere lives entirely in the first 32 B (
     float    gb[2];         // rect: b1,c
     float    rot[6];        // sinx,cosx,siny,cosy,sinz,cosz
 };
+// A primitive in CHAIN FORM (include/mirt.h "general instance chains": a leaf with any nesting of TranslatedInstance /
+// RotatedInstance around it) reuses the record: off = SphereHitable::m_center, info bit 9 set, bits 16-19 = number of ops,
+// rot[0] = (as bits) index of its first OpRec; ops are stored outermost first.
+struct OpRec { uint32_t kind; float a, b, c; };   // 16 B: MIRT_OP_TRANSLATE: offset a,b,c; MIRT_OP_ROTATE_X/Y/Z: sin a, cos b
 struct Node2 {              // 64 B: both children's boxes in the parent, for near-first traversal
     float   lmn[3]; int32_t left;
     float   lmx[3]; int32_t right;
@@ -248,6 +252,8 @@ struct TexRec { uint32_t w, h, offset, pad; };   // offset: first texel in the R
 #define PI_CAX(i)    (((i) >> 5) & 3u)
 #define PI_REV(i)    (((i) >> 7) & 1u)
 #define PI_ROT(i)    (((i) >> 8) & 1u)
+#define PI_CHAIN(i)  (((i) >> 9) & 1u)
+#define PI_NOPS(i)   (((i) >> 16) & 15u)
 
 struct Hit { float t; f3 pos, nrm; float u, v; int32_t mat, prim; };
 
@@ -302,9 +308,25 @@ __device__ __forceinline__ void rot_out(f3 &p, f3 &n, uint32_t ax, float s, floa
 // with a live rotation, RotZ, RotY, RotX (outermost first; SimpleObject.cpp:173-181).
 // A rotation chain whose three angles are 0 is skipped: 1*x + (+-0)*y == x for finite input, so
 // only the sign of a zero can differ.
-template <class P>
-__device__ __forceinline__ void to_leaf_space(const P &pr, uint32_t info, f3 &o, f3 &d)
+// CHAIN (kernel variants for scenes that hold chain-form primitives; the others compile none of it): a primitive in chain form
+// passes the ray through its ops, outermost first -- TranslatedInstance::Hit (Hitables.cpp:166) and RotatedInstance::Hit
+// (:244-250) each transform the ray and call their child.
+typedef float opf4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) opf4_t *OpPtr;            // one 16-byte global load per op
+struct OpVal { uint32_t kind; float a, b, c; };
+__device__ __forceinline__ OpVal load_op(const OpRec *ops, uint32_t i) { const opf4_t q = ((OpPtr)ops)[i]; OpVal v; v.kind = __float_as_uint(q.x); v.a = q.y; v.b = q.z; v.c = q.w; return v; }
+template <bool CHAIN = false, class P>
+__device__ __forceinline__ void to_leaf_space(const P &pr, uint32_t info, f3 &o, f3 &d, const OpRec *ops = nullptr)
 {
+    if (CHAIN && PI_CHAIN(info)) {
+        const uint32_t first = __float_as_uint(pr.rot[0]), n = PI_NOPS(info);
+        for (uint32_t k = 0; k < n; ++k) {
+            const OpVal op = load_op(ops, first + k);
+            if (op.kind == MIRT_OP_TRANSLATE) o = o - mk(op.a, op.b, op.c);
+            else rot_in(o, d, op.kind - 1u, op.a, op.b);
+        }
+        return;
+    }
     o = o - mk(pr.off[0], pr.off[1], pr.off[2]);
     if (PI_ROT(info)) {
         rot_in(o, d, 2, pr.rot[4], pr.rot[5]);
@@ -316,15 +338,17 @@ __device__ __forceinline__ void to_leaf_space(const P &pr, uint32_t info, f3 &o,
 // t of the closest accepted intersection of one primitive, or false.  Sphere: Hitables.cpp:20-43
 // (centre 0, SimpleObject.cpp:136); rect: Hitables.cpp:95-100.  a_dd = dot(dir,dir) is passed in
 // because it does not depend on the primitive when no rotation is live.
-template <class P>
-__device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, float t_max, float &t_out)
+template <bool CHAIN = false, class P>
+__device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, float t_max, float &t_out, const OpRec *ops = nullptr)
 {
     uint32_t info = pr.info;
-    to_leaf_space(pr, info, o, d);
+    to_leaf_space<CHAIN>(pr, info, o, d, ops);
     if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
+        f3 oc = o;                                                       // Hitables.cpp:20; the factory form's sphere sits at 0
+        if (CHAIN && PI_CHAIN(info)) oc = o - mk(pr.off[0], pr.off[1], pr.off[2]);
         float a = dot(d, d);
-        float b = 2.0f * dot(d, o);
-        float c = dot(o, o) - pr.ga[2];
+        float b = 2.0f * dot(d, oc);
+        float c = dot(oc, oc) - pr.ga[2];
         float disc = b * b - 4 * a * c;
         bool in = false;
         if (disc > 0) {                                                  // one exit, flags instead of early returns
@@ -401,17 +425,20 @@ __device__ __forceinline__ float det_asinf(float x)
 // on the way out: :253-260 per rotation, :169 translate).  Recomputed from (prim, t): every step
 // is a deterministic function of the same inputs, so the bits equal the reference's in-place
 // record.  with_uv additionally evaluates CalculateUV (Hitables.cpp:62-78) / the rect's u,v.
-template <class P>
-__device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 d, float t, bool with_uv, Hit &h)
+template <bool CHAIN = false, class P>
+__device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 d, float t, bool with_uv, Hit &h, const OpRec *ops = nullptr)
 {
     uint32_t info = pr.info;
-    to_leaf_space(pr, info, o, d);
+    const bool chain = CHAIN && PI_CHAIN(info);
+    to_leaf_space<CHAIN>(pr, info, o, d, ops);
     h.t = t; h.mat = (int32_t)pr.mat; h.prim = prim; h.u = 0.0f; h.v = 0.0f;
     h.pos = ray_at(o, d, t);
     if (PI_KIND(info) == MIRT_PRIM_SPHERE) {
-        h.nrm = scale(h.pos, pr.ga[1]);                         // (pos - 0) / r == * (1.f/r), Vec3.h:85-88
+        f3 rel = h.pos;                                         // pos - m_center, Hitables.cpp:37,65
+        if (chain) rel = h.pos - mk(pr.off[0], pr.off[1], pr.off[2]);
+        h.nrm = scale(rel, pr.ga[1]);                           // (pos - centre) / r == * (1.f/r), Vec3.h:85-88
         if (with_uv) {
-            f3 p = normalize(h.pos);
+            f3 p = normalize(rel);
             float theta = det_atan2f(p.z, p.x);
             float phi = det_asinf(p.y);
             const float PI = 3.14159265358979323846f;
@@ -428,11 +455,20 @@ __device__ __forceinline__ void prim_record(const P &pr, int32_t prim, f3 o, f3 
         }
         const float sgn = PI_REV(info) ? -1.0f : 1.0f;                   // selects, not the branches of set()
         h.nrm = mk(cA == 0 ? sgn : 0.0f, cA == 1 ? sgn : 0.0f, cA >= 2 ? sgn : 0.0f);
-        if (PI_ROT(info)) {
+        if (!chain && PI_ROT(info)) {
             rot_out(h.pos, h.nrm, 0, pr.rot[0], pr.rot[1]);
             rot_out(h.pos, h.nrm, 1, pr.rot[2], pr.rot[3]);
             rot_out(h.pos, h.nrm, 2, pr.rot[4], pr.rot[5]);
         }
+    }
+    if (chain) {                                                // the record on its way back out, innermost instance first (:169, :253-260)
+        const uint32_t first = __float_as_uint(pr.rot[0]), n = PI_NOPS(info);
+        for (uint32_t k = n; k-- > 0;) {
+            const OpVal op = load_op(ops, first + k);
+            if (op.kind == MIRT_OP_TRANSLATE) h.pos = h.pos + mk(op.a, op.b, op.c);
+            else rot_out(h.pos, h.nrm, op.kind - 1u, op.a, op.b);
+        }
+        return;
     }
     h.pos = h.pos + mk(pr.off[0], pr.off[1], pr.off[2]);
 }

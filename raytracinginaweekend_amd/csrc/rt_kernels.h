@@ -60,6 +60,7 @@ struct SceneDev {
     const float4  *sph4;                          // scenes of single unrotated spheres only (else NULL): (centre, r*r) per object -- all a leaf test reads, in ONE 16-byte access
     const uint2   *objs;   uint32_t n_objects;   // (first, count)
     const MatRec  *mats;   uint32_t n_mats;
+    const OpRec   *ops;                           // instances of chain-form primitives (rt_device.h OpRec), NULL when the scene has none
     int32_t root;
     float   ambient[3];
     // dynamic-LDS plan (in records): [prims][nodes][mats][stack]
@@ -232,7 +233,7 @@ __device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end,
 // spheres, everything else), each class by its own loop with the axes fixed at compile time and nothing to classify
 // per primitive.  Walking out of order is safe because acceptance carries the scene index:
 // "t <= t_max, a later primitive wins a tie" == "t < t_max || (t == t_max && index > best)" whatever the order.
-template <bool PLDS>
+template <bool PLDS, bool CHAIN = false>
 __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
                                                 float t_min, float &t_max)
 {
@@ -306,7 +307,7 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         pr.gb[0] = __uint_as_float(q2.x); pr.gb[1] = __uint_as_float(q2.y); pr.rot[0] = __uint_as_float(q2.z); pr.rot[1] = __uint_as_float(q2.w);
         pr.rot[2] = __uint_as_float(q3.x); pr.rot[3] = __uint_as_float(q3.y); pr.rot[4] = __uint_as_float(q3.z); pr.rot[5] = __uint_as_float(q3.w);
         float t;
-        if (prim_t(pr, o, d, t_min, t_max, t) && (t < t_max || (int32_t)pr.mat > best)) { t_max = t; best = (int32_t)pr.mat; }
+        if (prim_t<CHAIN>(pr, o, d, t_min, t_max, t, sc.ops) && (t < t_max || (int32_t)pr.mat > best)) { t_max = t; best = (int32_t)pr.mat; }
     }
     return best;
 }
@@ -344,7 +345,7 @@ __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f
 // LDS ([level][lane] so a level is one conflict-free row); nodes with index < lds_nodes (the top
 // levels, nodes are numbered breadth-first at upload) are read from LDS, deeper ones from HBM as
 // one 32-byte record per lane.
-template <bool PLDS>
+template <bool PLDS, bool CHAIN = false>
 __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView &v, f3 o, f3 d,
                                                float t_min, float &t_max)
 {
@@ -374,7 +375,7 @@ __device__ __forceinline__ int32_t closest_bvh(const SceneDev &sc, const LdsView
             for (uint32_t i = 0; i < ob.y; ++i) {
                 float t;
                 uint32_t p = ob.x + i;
-                if (prim_t(P[p], o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)p; }
+                if (prim_t<CHAIN>(P[p], o, d, t_min, t_max, t, sc.ops)) { t_max = t; best = (int32_t)p; }
             }
         }
         if (stk.sp == 0) break;
@@ -399,10 +400,10 @@ typedef const __attribute__((address_space(1))) u32x2_t *GlobalU2;
 // (the sphere branch fetched r*r only after the kind had arrived and been tested: two memory round trips per leaf pass), so the
 // first 32 bytes -- all a sphere needs, one sector -- are fetched together and pinned in front of the test; what only rects and
 // rotated primitives need stays lazy.  Same arithmetic as prim_t on the record in memory.
-template <bool PLDS>
-__device__ __forceinline__ bool leaf_prim_t(const Prims<PLDS> &P, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t)
+template <bool PLDS, bool CHAIN = false>
+__device__ __forceinline__ bool leaf_prim_t(const Prims<PLDS> &P, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t, const OpRec *ops = nullptr)
 {
-    if constexpr (PLDS) return prim_t(P[p], o, d, t_min, t_max, t);
+    if constexpr (PLDS) return prim_t<CHAIN>(P[p], o, d, t_min, t_max, t, ops);
     else {
         const GlobalF4 g = (GlobalF4)&P[p];
         f32x4_t r0 = g[0], r1 = g[1];
@@ -416,7 +417,8 @@ __device__ __forceinline__ bool leaf_prim_t(const Prims<PLDS> &P, uint32_t p, f3
 #pragma unroll
             for (int k = 0; k < 6; ++k) pr.rot[k] = P[p].rot[k];
         }
-        return prim_t(pr, o, d, t_min, t_max, t);
+        if (CHAIN && (pr.info & 0x200u)) pr.rot[0] = P[p].rot[0];                 // chain form: where its ops start
+        return prim_t<CHAIN>(pr, o, d, t_min, t_max, t, ops);
     }
 }
 
@@ -477,7 +479,7 @@ __device__ __forceinline__ void fetch_node2(const Node2 *nodes2, uint32_t n_node
 // records tested in a loop -- were built too, with the oracle's twin: 11 % fewer node steps per ray but 1.8x the sphere tests, and
 // those run in the leaf passes, where few lanes take part: 5 % slower on 485 spheres, 1.5 % on 1 M.  Numbers in
 // profiles/r03_trace_ablation.txt; this is round 2's form.)
-template <bool PLDS>
+template <bool PLDS, bool CHAIN = false>
 __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, float &t_max, uint32_t leaf_want)
 {
     int32_t best = -1;
@@ -526,7 +528,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
                     if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
                     for (uint32_t i = 0; i < cnt; ++i) {
                         float t;
-                        if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, t_max, t)) { t_max = t; best = (int32_t)(first + i); }
+                        if (leaf_prim_t<PLDS, CHAIN>(P, first + i, o, d, t_min, t_max, t, sc.ops)) { t_max = t; best = (int32_t)(first + i); }
                     }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
@@ -543,7 +545,7 @@ struct WalkState { int32_t cur, best; float t_max; uint32_t sp; f3 invd; };
 // copy under an explicit per-lane branch -- ds_read, not a flat load, so those steps make no L1 access at all.  Pays where the walk
 // waits on memory (1 M spheres +3.5 % with 32 nodes; 8/16/64: +1.5/+2.5/+2 %, 128 and more lose to the LDS they take); the branch
 // costs the 485-sphere walk, which is issue-bound, 1-2 %, hence a variant of its own.
-template <bool PLDS, bool LTOP>
+template <bool PLDS, bool LTOP, bool CHAIN = false>
 __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v, f3 o, f3 d, float t_min, WalkState &w, uint32_t want, uint32_t leaf_want)
 {
     // a lane takes part while w.cur != MIRT_CHILD_NONE (closest_bvh2's end mark); lanes that hold no walk enter with the mark
@@ -594,7 +596,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
                     if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
                     for (uint32_t i = 0; i < cnt; ++i) {
                         float t;
-                        if (leaf_prim_t<PLDS>(P, first + i, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = (int32_t)(first + i); }
+                        if (leaf_prim_t<PLDS, CHAIN>(P, first + i, o, d, t_min, w.t_max, t, sc.ops)) { w.t_max = t; w.best = (int32_t)(first + i); }
                     }
                 }
                 if (stk.sp == 0) cur = MIRT_CHILD_NONE; else cur = stk.pop();
@@ -936,7 +938,8 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// TEX: the scene has image textures -- hits carry u,v (CalculateUV's atan2f/asinf for spheres) and the albedo is fetched
+// FULL: the kernel variants for scenes with image textures (hits carry u,v -- CalculateUV's atan2f/asinf for spheres -- and the
+// albedo is fetched) and/or primitives in chain form (general instance chains, rt_device.h); plain scenes compile neither
 #ifndef MIRT_LIST_STASH
 #define MIRT_LIST_STASH 128u
 #endif
@@ -958,7 +961,7 @@ __device__ __forceinline__ const TraceArgs &late_args()
     return *(const TraceArgs *)kp;
 }
 
-template <int ACCEL, bool PLDS, bool TEX>
+template <int ACCEL, bool PLDS, bool FULL>
 __device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1012,7 +1015,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     WalkState ws; ws.cur = MIRT_CHILD_NONE; ws.best = -1; ws.t_max = 0.0f; ws.sp = 0; ws.invd = mk(0, 0, 0);   // ACCEL 3 only; cur: no walk under way
 
     // ---- second stream: metal / dielectric vertices are parked (after their draws) and shaded 64 at a time
-    constexpr bool DEFER = MIRT_DEFER_MD && ACCEL == 0 && !TEX;
+    constexpr bool DEFER = MIRT_DEFER_MD && ACCEL == 0 && !FULL;
     uint32_t q_cnt = 0, r_cnt = 0;                                   // wave-uniform: parked vertices, ready rays
     const uint32_t gwave = blockIdx.x * (MIRT_BLOCK / 64) + wave;
     float4 *const mdq = DEFER ? a.mdq + (size_t)gwave * MDQ_PLANES * MDQ_CAP : nullptr;
@@ -1174,7 +1177,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                     ws.cur = a.sc.root; ws.best = -1; ws.t_max = 3.402823466e+38f; ws.sp = 0;
                     ws.invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
                 }
-                bvh2_slice<PLDS, ACCEL == 4>(a.sc, lv, o, d, 0.001f, ws, a.slice_want, a.leaf_want);
+                bvh2_slice<PLDS, ACCEL == 4, FULL>(a.sc, lv, o, d, 0.001f, ws, a.slice_want, a.leaf_want);
             }
             ready = live && ws.cur == MIRT_CHILD_NONE;
         }
@@ -1183,13 +1186,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             const float t_min = 0.001f;
             int32_t best;
             if constexpr (ACCEL >= 3) { best = ws.best; t_max = ws.t_max; }
-            else best = ACCEL == 2 ? closest_bvh2<PLDS>(a.sc, lv, o, d, t_min, t_max, a.leaf_want)
-                      : (ACCEL == 1 ? closest_bvh<PLDS>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS>(a.sc, lv, o, d, t_min, t_max));
+            else best = ACCEL == 2 ? closest_bvh2<PLDS, FULL>(a.sc, lv, o, d, t_min, t_max, a.leaf_want)
+                      : (ACCEL == 1 ? closest_bvh<PLDS, FULL>(a.sc, lv, o, d, t_min, t_max) : closest_list<PLDS, FULL>(a.sc, lv, o, d, t_min, t_max));
             if (best < 0) {                                                        // :186
                 radiance = thr * mk(a.sc.ambient[0], a.sc.ambient[1], a.sc.ambient[2]); done = true;
             } else {
                 const Prims<PLDS> P(a.sc, lv);
-                prim_record(P[best], best, o, d, t_max, TEX, h);
+                prim_record<FULL>(P[best], best, o, d, t_max, FULL && a.sc.n_textures != 0u, h, a.sc.ops);
                 if (a.flags & MIRT_FLAG_NORMAL_DISPLAY) {                          // :164-167
                     radiance = scale(mk(h.nrm.x + 1.0f, h.nrm.y + 1.0f, h.nrm.z + 1.0f), 0.5f); done = true;
                 } else if (!(depth < a.max_depth)) {                               // :173-174
@@ -1233,7 +1236,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         }
         if (ready && !done && !parked && !retry) {
             Scat s;
-            const f3 albedo = TEX ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
+            const f3 albedo = (FULL && a.sc.n_textures != 0u) ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
             scatter_finish<ACCEL != 0, DEFER ? 1 : 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
@@ -1639,10 +1642,10 @@ __global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST2_WAVES) k_trace2(TraceAr
 // The list walk is VALU-bound and compiled for 7 waves per SIMD (72 VGPRs, no spill; 8 would spill and lose).  The
 // BVH walks are bound by the CU's L1 and indifferent to 6..8 waves: 8 (64 VGPRs) for the plain walks, 6 for the
 // yielding one, which keeps its walk state in registers through the shading code.  All launch with a small LDS plan.
-template <bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, TEX>(a); }
-template <int ACCEL, bool PLDS, bool TEX>
-__global__ void __launch_bounds__(MIRT_BLOCK, ACCEL >= 3 ? MIRT_YIELD_WAVES : MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, TEX>(a); }
+template <bool PLDS, bool FULL>
+__global__ void __launch_bounds__(MIRT_BLOCK, MIRT_LIST_WAVES) k_trace(TraceArgs a) { trace_body<0, PLDS, FULL>(a); }
+template <int ACCEL, bool PLDS, bool FULL>
+__global__ void __launch_bounds__(MIRT_BLOCK, ACCEL >= 3 ? MIRT_YIELD_WAVES : MIRT_BVH_WAVES) k_trace_bvh(TraceArgs a) { trace_body<ACCEL, PLDS, FULL>(a); }
 
 // ---------------------------------------------------------------------------------- accumulate
 // HomemadeRayTracer.cpp:125-133: col += Sample(...) in sample order.  sum is W*H*3 (interleaved).
@@ -1723,8 +1726,8 @@ __global__ void k_prim_hit_batch(SceneDev sc, uint32_t prim, const float *org, c
     if (i >= nray) return;
     f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
     float t; Hit h;
-    bool hit = prim_t(sc.prims[prim], o, d, t_min, t_max, t);
-    if (hit) prim_record(sc.prims[prim], (int32_t)prim, o, d, t, true, h);
+    bool hit = prim_t<true>(sc.prims[prim], o, d, t_min, t_max, t, sc.ops);
+    if (hit) prim_record<true>(sc.prims[prim], (int32_t)prim, o, d, t, true, h, sc.ops);
     store_hit(out + i, h, hit);
 }
 
@@ -1738,11 +1741,11 @@ __global__ void __launch_bounds__(MIRT_BLOCK) k_world_hit_batch(SceneDev sc, con
     for (uint32_t i = blockIdx.x * MIRT_BLOCK + threadIdx.x; i < nray; i += gridDim.x * MIRT_BLOCK) {
         f3 o = mk(org[3 * i], org[3 * i + 1], org[3 * i + 2]), d = mk(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]);
         float tm = t_max;
-        int32_t best = ACCEL == 2 ? closest_bvh2<PLDS>(sc, lv, o, d, t_min, tm, MIRT_LEAF_WANT)
-                     : (ACCEL == 1 ? closest_bvh<PLDS>(sc, lv, o, d, t_min, tm) : closest_list<PLDS>(sc, lv, o, d, t_min, tm));
+        int32_t best = ACCEL == 2 ? closest_bvh2<PLDS, true>(sc, lv, o, d, t_min, tm, MIRT_LEAF_WANT)
+                     : (ACCEL == 1 ? closest_bvh<PLDS, true>(sc, lv, o, d, t_min, tm) : closest_list<PLDS, true>(sc, lv, o, d, t_min, tm));
         Hit h;
         const Prims<PLDS> P(sc, lv);
-        if (best >= 0) prim_record(P[best], best, o, d, tm, true, h);
+        if (best >= 0) prim_record<true>(P[best], best, o, d, tm, true, h, sc.ops);
         store_hit(out + i, h, best >= 0);
     }
 }

@@ -47,9 +47,28 @@ inline Box rot_box(const Box &in, uint32_t axis, float sn, float cs)  // Hitable
     }
     return r;
 }
-inline Box object_box(const mirt_scene &s, uint32_t obj)
+inline bool chain_form(const mirt_scene &s, uint32_t p) { return s.prim_chain && s.prim_chain[p] != 0; }
+// A chain-form primitive's box: the leaf's, carried through its instances from the innermost out (Hitables.cpp:175-180, :208-238).
+// A sphere's is the box around ITS CENTRE: the reference's SphereHitable::BoundingBox (Hitables.cpp:56-60) forgets m_center, which
+// is harmless for its factories (centre 0) and wrong for any other sphere; these boxes serve the library's own builder and the
+// object boxes of the near-first walk, which must contain what they guard.
+inline Box prim_box_chain(const mirt_scene &s, uint32_t p)
 {
-    uint32_t first = s.obj_first[obj], cnt = s.obj_count[obj];
+    Box b;
+    if (s.prim_kind[p] == MIRT_PRIM_SPHERE) {
+        const float r = s.prim_geom[5 * (size_t)p];
+        for (int i = 0; i < 3; ++i) { b.mn[i] = s.prim_center[3 * (size_t)p + i] - r; b.mx[i] = s.prim_center[3 * (size_t)p + i] + r; }
+    } else b = rect_box(s, p);
+    const uint32_t first = s.prim_chain[p] - 1u, n = s.prim_nops[p];
+    for (uint32_t k = n; k-- > 0;) {
+        const uint32_t kind = s.op_kind[first + k]; const float *a = s.op_arg + 3 * (size_t)(first + k);
+        if (kind == MIRT_OP_TRANSLATE) { for (int i = 0; i < 3; ++i) { b.mn[i] = b.mn[i] + a[i]; b.mx[i] = b.mx[i] + a[i]; } }
+        else b = rot_box(b, kind - 1u, a[0], a[1]);
+    }
+    return b;
+}
+inline Box object_box_factory(const mirt_scene &s, uint32_t first, uint32_t cnt)
+{
     Box b;
     if (s.prim_kind[first] == MIRT_PRIM_SPHERE) {                      // Hitables.cpp:56-60
         float r = s.prim_geom[5 * (size_t)first];
@@ -63,6 +82,19 @@ inline Box object_box(const mirt_scene &s, uint32_t obj)
         }
     }
     for (int i = 0; i < 3; ++i) { b.mn[i] = b.mn[i] + s.prim_off[3 * (size_t)first + i]; b.mx[i] = b.mx[i] + s.prim_off[3 * (size_t)first + i]; }  // :175-180
+    return b;
+}
+// An object of factory-form primitives is one of the factories' shapes (a sphere, a rect, a cube's six faces inside ONE chain): its
+// box is built the way the reference builds it, combo first, then the chain.  An object with a chain-form primitive is a general
+// combo: the union, in order, of its primitives' boxes (Hitables.cpp:152-161).
+inline Box object_box(const mirt_scene &s, uint32_t obj)
+{
+    const uint32_t first = s.obj_first[obj], cnt = s.obj_count[obj];
+    bool any_chain = false;
+    for (uint32_t i = 0; i < cnt; ++i) any_chain |= chain_form(s, first + i);
+    if (!any_chain) return object_box_factory(s, first, cnt);
+    Box b = chain_form(s, first) ? prim_box_chain(s, first) : object_box_factory(s, first, 1);
+    for (uint32_t i = 1; i < cnt; ++i) b = combine(chain_form(s, first + i) ? prim_box_chain(s, first + i) : object_box_factory(s, first + i, 1), b);
     return b;
 }
 
@@ -152,8 +184,18 @@ inline std::string validate(const mirt_scene &s)
         if (s.obj_first[o] != next || s.obj_count[o] == 0) return "objects must be consecutive non-empty runs of primitives";
         if (s.obj_count[o] > s.n_prims - next) return "objects do not cover the primitives";
         next += s.obj_count[o];
-        for (uint32_t i = 1; i < s.obj_count[o]; ++i)
-            if (s.prim_kind[s.obj_first[o] + i] != MIRT_PRIM_RECT || s.prim_kind[s.obj_first[o]] != MIRT_PRIM_RECT) return "a multi-primitive object must be rects (HitableCombo of a cube)";
+        // several factory-form primitives in one object are a cube: six rects inside ONE chain (SimpleObject.cpp:261-276), which is
+        // how their box is built; a general combo brings its primitives in chain form
+        bool chains = false;
+        for (uint32_t i = 0; i < s.obj_count[o]; ++i) chains |= s.prim_chain && s.prim_chain[s.obj_first[o] + i] != 0;
+        for (uint32_t i = 1; !chains && i < s.obj_count[o]; ++i) {
+            const uint32_t f = s.obj_first[o], p = f + i;
+            if (s.prim_kind[p] != MIRT_PRIM_RECT || s.prim_kind[f] != MIRT_PRIM_RECT) return "a multi-primitive object of factory-form primitives must be rects (HitableCombo of a cube); general combos use chain form";
+            bool same = ((s.prim_axes[p] >> 7) & 1) == ((s.prim_axes[f] >> 7) & 1);
+            for (int k = 0; k < 3; ++k) same &= s.prim_off[3 * (size_t)p + k] == s.prim_off[3 * (size_t)f + k];
+            for (int k = 0; k < 6; ++k) same &= s.prim_rot[6 * (size_t)p + k] == s.prim_rot[6 * (size_t)f + k];
+            if (!same) return "the factory-form primitives of one object must share their instance chain (a cube's faces do); general combos use chain form";
+        }
     }
     if (next != s.n_prims) return "objects do not cover the primitives";
     for (uint32_t p = 0; p < s.n_prims; ++p) {
@@ -162,6 +204,15 @@ inline std::string validate(const mirt_scene &s)
         if (s.prim_kind[p] == MIRT_PRIM_RECT) {
             uint32_t ax = s.prim_axes[p], a = ax & 3, b = (ax >> 2) & 3, c = (ax >> 4) & 3;
             if (a > 2 || b > 2 || c > 2 || a == b || a == c || b == c) return "bad rect axes";
+        }
+    }
+    if (s.prim_chain) {
+        if (!s.prim_nops || !s.prim_center || (s.n_ops && (!s.op_kind || !s.op_arg))) return "null instance-chain array";
+        for (uint32_t p = 0; p < s.n_prims; ++p) {
+            if (!s.prim_chain[p]) continue;
+            if (s.prim_nops[p] > MIRT_MAX_CHAIN_OPS) return "instance chain longer than MIRT_MAX_CHAIN_OPS";
+            if ((uint64_t)(s.prim_chain[p] - 1u) + s.prim_nops[p] > s.n_ops) return "instance chain out of range";
+            for (uint32_t k = 0; k < s.prim_nops[p]; ++k) if (s.op_kind[s.prim_chain[p] - 1u + k] > MIRT_OP_ROTATE_Z) return "bad instance op";
         }
     }
     for (uint32_t m = 0; m < s.n_mats; ++m) if (s.mat_kind[m] > 3) return "bad material kind";

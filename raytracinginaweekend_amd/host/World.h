@@ -21,6 +21,9 @@ enum WorldID
 	// the two image-textured materials the reference defines but no shipped world uses (Resouces.cpp:166-176):
 	// a soil-textured floor and back wall, a checker-plate metal ball, a white light, sky ambient
 	WORLD_ID_TEXTURED,
+	// the hitable vocabulary beyond the factories' shapes (Hitables.h:20-106 compose freely): a sphere with its own centre inside
+	// a rotation inside a translation, combos of spheres, nested combos under instances, rotations out of the factories' z,y,x order
+	WORLD_ID_CHAINS,
 };
 
 class World

@@ -106,24 +106,49 @@ int32_t FlatScene::TextureIndex(const ITexture2D *t)
 	m_texIndex[t] = row;
 	return row;
 }
-void FlatScene::PushCommon(const InstanceChain &c, uint32_t kind, uint32_t axes, const IMaterial *m)
+void FlatScene::PushCommon(uint32_t kind, uint32_t axes, const IMaterial *m, const float off[3], const float rot[6])
 {
 	if (obj_first.empty()) throw std::runtime_error("FlatScene: primitive outside an object");
 	prim_kind.push_back(kind); prim_axes.push_back(axes); prim_mat.push_back(MaterialIndex(m));
-	for (int i = 0; i < 3; ++i) prim_off.push_back(c.off[i]);
-	for (int i = 0; i < 6; ++i) prim_rot.push_back(c.rot[i]);
+	for (int i = 0; i < 3; ++i) prim_off.push_back(off[i]);
+	for (int i = 0; i < 6; ++i) prim_rot.push_back(rot[i]);
+	prim_chain.push_back(0); prim_nops.push_back(0);
+	for (int i = 0; i < 3; ++i) prim_center.push_back(0.0f);
 	obj_count.back()++;
 }
-void FlatScene::AddSphere(const InstanceChain &c, float radius, const IMaterial *m)
+// turns the primitive pushed last into chain form: its instances, outermost first, and the sphere's own centre
+void FlatScene::PushChain(const InstanceChain &c, const float center[3])
 {
-	if (c.has_rot) throw std::runtime_error("FlatScene: rotated spheres are not representable (a sphere at its own centre is rotation-invariant; drop the RotatedInstance)");
-	PushCommon(c, MIRT_PRIM_SPHERE, 0, m);
+	if (c.ops.size() > MIRT_MAX_CHAIN_OPS)
+		throw std::runtime_error("FlatScene: a leaf hitable inside " + std::to_string(c.ops.size()) + " nested instances; the device takes " + std::to_string(MIRT_MAX_CHAIN_OPS));
+	prim_chain.back() = (uint32_t)op_kind.size() + 1u; prim_nops.back() = (uint32_t)c.ops.size();
+	for (int i = 0; i < 3; ++i) prim_center[prim_center.size() - 3 + i] = center[i];
+	for (const InstanceOp &o : c.ops) { op_kind.push_back(o.kind); op_arg.push_back(o.a); op_arg.push_back(o.b); op_arg.push_back(o.c); }
+}
+static const float kNoOffset[3] = { 0.0f, 0.0f, 0.0f }, kNoRotation[6] = { 0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 1.0f };
+void FlatScene::AddSphere(const InstanceChain &c, const float center[3], float radius, const IMaterial *m)
+{
+	// SimpleObjectSphere's shape, Translate(Sphere at 0) (SimpleObject.cpp:136): the factory form
+	const bool factory = !c.force_chain && c.ops.size() == 1 && c.ops[0].kind == MIRT_OP_TRANSLATE && center[0] == 0.0f && center[1] == 0.0f && center[2] == 0.0f;
+	const float off[3] = { factory ? c.ops[0].a : 0.0f, factory ? c.ops[0].b : 0.0f, factory ? c.ops[0].c : 0.0f };
+	PushCommon(MIRT_PRIM_SPHERE, 0, m, off, kNoRotation);
 	prim_geom.push_back(radius); for (int i = 0; i < 4; ++i) prim_geom.push_back(0.0f);
+	if (!factory) PushChain(c, center);
 }
 void FlatScene::AddRect(const InstanceChain &c, uint32_t aA, uint32_t bA, uint32_t cA, float a0, float a1, float b0, float b1, float cc, bool reverse, const IMaterial *m)
 {
-	PushCommon(c, MIRT_PRIM_RECT, MIRT_AXES_PACK(aA, bA, cA, reverse ? 1u : 0u, c.has_rot ? 1u : 0u), m);
+	// SimpleObjectRect / SimpleObjectCube's shape, Translate(RotZ(RotY(RotX(Rect)))) (SimpleObject.cpp:173-181), a bare rect, or a
+	// rect that is only translated: the factory form
+	const size_t n = c.ops.size();
+	bool full = n == 4 && c.ops[0].kind == MIRT_OP_TRANSLATE && c.ops[1].kind == MIRT_OP_ROTATE_Z && c.ops[2].kind == MIRT_OP_ROTATE_Y && c.ops[3].kind == MIRT_OP_ROTATE_X;
+	const bool factory = !c.force_chain && (full || n == 0 || (n == 1 && c.ops[0].kind == MIRT_OP_TRANSLATE));
+	if (!factory) full = false;
+	float off[3] = { 0.0f, 0.0f, 0.0f }, rot[6] = { 0.0f, 1.0f, 0.0f, 1.0f, 0.0f, 1.0f };
+	if (factory && n) { off[0] = c.ops[0].a; off[1] = c.ops[0].b; off[2] = c.ops[0].c; }
+	if (full) { rot[0] = c.ops[3].a; rot[1] = c.ops[3].b; rot[2] = c.ops[2].a; rot[3] = c.ops[2].b; rot[4] = c.ops[1].a; rot[5] = c.ops[1].b; }
+	PushCommon(MIRT_PRIM_RECT, MIRT_AXES_PACK(aA, bA, cA, reverse ? 1u : 0u, full ? 1u : 0u), m, off, rot);
 	prim_geom.push_back(a0); prim_geom.push_back(a1); prim_geom.push_back(b0); prim_geom.push_back(b1); prim_geom.push_back(cc);
+	if (!factory) PushChain(c, kNoOffset);
 }
 void FlatScene::EndObject()
 {
@@ -143,6 +168,8 @@ mirt_scene FlatScene::View() const
 	for (int i = 0; i < 3; ++i) s.ambient[i] = ambient[i];
 	s.n_textures = (uint32_t)tex_width.size(); s.tex_width = tex_width.data(); s.tex_height = tex_height.data(); s.tex_offset = tex_offset.data();
 	s.tex_rgba8 = tex_rgba8.data(); s.mat_texture = mat_texture.data();
+	bool chains = false; for (uint32_t k : prim_chain) chains |= k != 0;
+	if (chains) { s.prim_chain = prim_chain.data(); s.prim_nops = prim_nops.data(); s.prim_center = prim_center.data(); s.n_ops = (uint32_t)op_kind.size(); s.op_kind = op_kind.data(); s.op_arg = op_arg.data(); }
 	return s;
 }
 
@@ -154,14 +181,8 @@ AABB SphereHitable::BoundingBox() const                                  // Hita
 }
 void SphereHitable::Flatten(FlatScene &out, const InstanceChain &chain) const
 {
-	if (m_center.x() != 0.0f || m_center.y() != 0.0f || m_center.z() != 0.0f) {
-		// a centre is a translation below the chain; fold it only when nothing else is there
-		if (chain.translated || chain.has_rot) throw std::runtime_error("SphereHitable: off-centre sphere inside an instance chain is not representable");
-		InstanceChain c = chain; c.translated = true; for (int i = 0; i < 3; ++i) c.off[i] = m_center[i];
-		out.AddSphere(c, m_radius, m_material);
-		return;
-	}
-	out.AddSphere(chain, m_radius, m_material);
+	const float c[3] = { m_center.x(), m_center.y(), m_center.z() };   // its own centre stays its own (Hitables.cpp:20,37,65): not a translation
+	out.AddSphere(chain, c, m_radius, m_material);
 }
 
 AxisAlignedRectHitable::AxisAlignedRectHitable(UINT32 aAxisIndex, UINT32 bAxisIndex, float a0, float a1, float b0, float b1, float c, BOOL reverseFace)
@@ -195,10 +216,13 @@ AABB HitableCombo::BoundingBox() const                                   // Hita
 }
 void HitableCombo::Flatten(FlatScene &out, const InstanceChain &chain) const
 {
-	for (UINT32 i = 0; i < m_hitableCount; ++i) {
-		if (!dynamic_cast<AxisAlignedRectHitable *>(m_hitableList[i])) throw std::runtime_error("HitableCombo: only rect faces are representable on the device");
-		m_hitableList[i]->Flatten(out, chain);
-	}
+	// HitableCombo::Hit (Hitables.cpp:130-142) tries its children in order with t_max shrinking, which is what an object's run of
+	// primitives does on the device; the instances above the combo apply to every child, nested combos unfold in place
+	// A combo of rects alone is a cube's (SimpleObject.cpp:261-276): its faces share the chain and may keep the factory form, whose
+	// object box is built combo first, chain second, like the reference's.  Any other combo hands its leaves over in chain form.
+	InstanceChain c = chain;
+	for (UINT32 i = 0; i < m_hitableCount; ++i) if (!dynamic_cast<AxisAlignedRectHitable *>(m_hitableList[i])) c.force_chain = true;
+	for (UINT32 i = 0; i < m_hitableCount; ++i) m_hitableList[i]->Flatten(out, c);
 }
 
 AABB TranslatedInstance::BoundingBox() const                             // Hitables.cpp:175-180
@@ -208,9 +232,8 @@ AABB TranslatedInstance::BoundingBox() const                             // Hita
 }
 void TranslatedInstance::Flatten(FlatScene &out, const InstanceChain &chain) const
 {
-	if (chain.translated || chain.has_rot) throw std::runtime_error("TranslatedInstance must be the outermost instance (Translate o RotZ o RotY o RotX o leaf)");
-	InstanceChain c = chain; c.translated = true;
-	for (int i = 0; i < 3; ++i) c.off[i] = m_offset[i];
+	InstanceChain c = chain;
+	c.ops.push_back(InstanceOp{ MIRT_OP_TRANSLATE, m_offset.x(), m_offset.y(), m_offset.z() });
 	m_hitable->Flatten(out, c);
 }
 
@@ -238,9 +261,8 @@ RotatedInstance::RotatedInstance(IHitable *hitable, float angle, UINT32 rotateAx
 }
 void RotatedInstance::Flatten(FlatScene &out, const InstanceChain &chain) const
 {
-	if ((int)m_cAxisIndex >= chain.innermost_axis) throw std::runtime_error("RotatedInstance chain must be ordered z, y, x from the outside in");
-	InstanceChain c = chain; c.has_rot = true; c.innermost_axis = (int)m_cAxisIndex;
-	c.rot[2 * m_cAxisIndex] = m_sinTheta; c.rot[2 * m_cAxisIndex + 1] = m_cosTheta;
+	InstanceChain c = chain;
+	c.ops.push_back(InstanceOp{ MIRT_OP_ROTATE_X + m_cAxisIndex, m_sinTheta, m_cosTheta, 0.0f });
 	m_hitable->Flatten(out, c);
 }
 
@@ -563,6 +585,48 @@ void World::ConstructWorld(WorldID wid, SimpleCamera *camera)            // Worl
 		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 3.0f, 0.0f), none, 1.5f, 1.5f, TRUE, nullptr, mat(MATERIAL_ID_LIGHTSOURCE_WHITE), this));
 		camera->Initialize(Vec3(0.0f, 1.5f, 5.0f), Vec3(0.0f, 0.7f, 0.0f), 35.0f, 1.0f, 10000.0f, 0.0f, 10.0f, 1.0f);
 		m_lightSources = new LightSources(this, objects, Vec3(0.5f, 0.6f, 0.8f));
+	} else if (wid == WORLD_ID_CHAINS) {
+		// scene code written against the reference's Hitables.h, no factory in sight: plain Objects whose m_hitable is any
+		// nesting of instances and combos (the combos' child arrays and children are owned by the object, as SimpleObjectCube
+		// owns its faces)
+		struct Built : Object {
+			std::vector<IHitable *> owned; std::vector<IHitable **> lists;
+			~Built() override { for (IHitable *h : owned) delete h; for (IHitable **l : lists) delete[] l; }
+			IHitable *combo(std::initializer_list<IHitable *> children) {
+				IHitable **l = new IHitable *[children.size()]; size_t n = 0;
+				for (IHitable *h : children) { l[n++] = h; owned.push_back(h); }
+				lists.push_back(l);
+				return new HitableCombo(l, (UINT32)children.size());
+			}
+		};
+		auto add = [&](Built *o, IHitable *h, const Vec3 &where, MaterialUniqueID id) {
+			o->m_world = this; o->m_translation = where; o->m_scaling = Vec3(1.0f, 1.0f, 1.0f); o->m_rotation = none;
+			o->m_hitable = h; o->m_material = mat(id); h->BindMaterial(o->m_material);
+			objects.push_back(o);
+		};
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, -2.0f, 0.0f), none, 12.0f, 12.0f, FALSE, nullptr, mat(MATERIAL_ID_LAMBERTIAN0), this));
+		objects.push_back(new SimpleObjectRect(XZ_RECT, Vec3(0.0f, 5.0f, 0.0f), Vec3(0.0f, 0.2f, 0.0f), 3.0f, 3.0f, TRUE, nullptr, mat(MATERIAL_ID_LIGHTSOURCE_WHITE), this));
+		{   // a sphere with its own centre, rotated, then translated
+			Built *o = new Built();
+			add(o, new TranslatedInstance(new RotatedInstance(new SphereHitable(Vec3(1.0f, 2.0f, 3.0f), 0.8f), 30.0f, 1), Vec3(0.25f, -0.5f, 0.125f)), Vec3(0.25f, -0.5f, 0.125f), MATERIAL_ID_METAL);
+		}
+		{   // a combo of two spheres
+			Built *o = new Built();
+			add(o, o->combo({ new SphereHitable(Vec3(-1.5f, 0.2f, 0.3f), 0.6f), new SphereHitable(Vec3(-0.9f, 0.5f, 0.1f), 0.5f) }), Vec3(-1.2f, 0.3f, 0.2f), MATERIAL_ID_LAMBERTIAN1);
+		}
+		{   // rotations out of the factories' order, a translation in the middle
+			Built *o = new Built();
+			add(o, new RotatedInstance(new TranslatedInstance(new RotatedInstance(new AxisAlignedRectHitable(0, 2, -0.8f, 0.8f, -0.6f, 0.6f, 0.1f, FALSE), 0.7f, 2), Vec3(0.4f, -1.0f, 0.9f)), -0.5f, 0),
+			    Vec3(0.4f, -1.0f, 0.9f), MATERIAL_ID_LAMBERTIAN2);
+		}
+		{   // nested combos under two instances: a glass ball, a small plate, and a pair of balls
+			Built *o = new Built();
+			IHitable *pair = o->combo({ new SphereHitable(Vec3(0.5f, 0.0f, 0.0f), 0.25f), new TranslatedInstance(new SphereHitable(Vec3(0.0f, 0.0f, 0.0f), 0.2f), Vec3(-0.5f, 0.1f, 0.0f)) });
+			IHitable *all = o->combo({ new SphereHitable(Vec3(0.0f, 0.0f, 0.0f), 0.4f), new TranslatedInstance(new AxisAlignedRectHitable(0, 1, -0.3f, 0.3f, -0.3f, 0.3f, 0.0f, FALSE), Vec3(0.0f, 0.6f, 0.0f)), pair });
+			add(o, new TranslatedInstance(new RotatedInstance(all, 1.1f, 1), Vec3(2.2f, -1.0f, 0.5f)), Vec3(2.2f, -1.0f, 0.5f), MATERIAL_ID_DIELECTRIC);
+		}
+		m_lightSources = new LightSources(this, objects, Vec3(0.6f, 0.7f, 0.9f));
+		camera->Initialize(Vec3(0.5f, 1.0f, 9.0f), Vec3(0.0f, 0.0f, 0.0f), 45.0f, 1.0f, 10000.0f, 0.05f, 10.0f, 1.0f);
 	} else {
 		throw std::invalid_argument("World::ConstructWorld: unknown world id");
 	}
@@ -902,6 +966,23 @@ mirt_host_world *mirt_host_world_create(int world_id, float aspect, uint64_t see
 const mirt_scene *mirt_host_world_scene(const mirt_host_world *h) { return &h->view; }
 const mirt_camera *mirt_host_world_camera(const mirt_host_world *h) { return &h->mcam; }
 void mirt_host_world_destroy(mirt_host_world *h) { if (!h) return; h->world.DeconstructWorld(); delete h->cam; delete h; }
+// what the flattener still refuses: a leaf under more than MIRT_MAX_CHAIN_OPS instances.  Builds Translate^n(Sphere) and flattens it;
+// returns 0 when it flattened (n_prims, n_ops and whether the primitive took the chain form go out), -1 with the message when refused.
+int mirt_host_try_chain(uint32_t n_translates, float cx, uint32_t *n_prims, uint32_t *n_ops, uint32_t *chain_form, char *err, size_t errlen)
+{
+	try {
+		IHitable *h = new SphereHitable(Vec3(cx, 0.0f, 0.0f), 0.5f);
+		for (uint32_t k = 0; k < n_translates; ++k) h = new TranslatedInstance(h, Vec3(0.125f, 0.0f, 0.0f));
+		Lambertian m(nullptr);
+		SimpleTexture2D_SingleColor grey(Vec3(0.5f, 0.5f, 0.5f));
+		m.m_albedo = &grey;
+		Object o; o.m_hitable = h; o.m_material = &m; h->BindMaterial(&m);
+		FlatScene flat;
+		o.Flatten(flat);
+		*n_prims = (uint32_t)flat.prim_kind.size(); *n_ops = (uint32_t)flat.op_kind.size(); *chain_form = flat.prim_chain[0] != 0;
+		return 0;
+	} catch (const std::exception &e) { if (err && errlen) { strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return -1; }
+}
 // whole reference flow: ConstructWorld -> TraceRay -> image bytes (and optionally <dir>/<name>.ppm)
 // scripted fly-through of the camera: frame f holds the (up to 4) key codes keys[4*f..4*f+3] (0 = none) for dt
 // seconds, then the camera is exported.  AutoFocus runs on the GPU.

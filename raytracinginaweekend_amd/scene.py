@@ -23,6 +23,7 @@ class FlatScene:
 
     def __init__(self, ambient=(0.0, 0.0, 0.0)):
         self.kind, self.off, self.geom, self.axes, self.rot, self.pmat = [], [], [], [], [], []
+        self.chain, self.center = [], []   # per primitive: None (factory form) or its instance ops, outermost first; SphereHitable::m_center
         self.obj_first, self.obj_count = [], []
         self.mkind, self.albedo, self.fuzz, self.ior, self.emit, self.mtex = [], [], [], [], [], []
         self.textures = []    # (h, w, 4) uint8 arrays, row 0 = top (SimpleTexture2D_TGAImage::m_pixelData)
@@ -59,10 +60,69 @@ class FlatScene:
         return self._mat(capi.MAT_DIFFUSE_LIGHT, emit=intensity)
 
     # ---- objects (SimpleObject.cpp) --------------------------------------------------------
-    def _prim(self, kind, off, geom, axes, rot, mat):
+    def _prim(self, kind, off, geom, axes, rot, mat, chain=None, center=(0.0, 0.0, 0.0)):
         self.kind.append(kind); self.off.append(off); self.geom.append(geom); self.axes.append(axes)
         self.rot.append(rot); self.pmat.append(mat)
+        self.chain.append(chain); self.center.append(tuple(float(x) for x in center))
         self._arrays = None
+
+    # ---- general hitables (Hitables.h:20-106 compose freely) -------------------------------
+    def hitable(self, tree, mat, force_chain=False):
+        """One Object whose m_hitable is `tree`, a nesting of
+            ("sphere", center, radius)                                  SphereHitable              Hitables.cpp:6-11
+            ("rect", aAxis, bAxis, a0, a1, b0, b1, c, reverse)          AxisAlignedRectHitable     :80-91
+            ("translate", child, offset)                                TranslatedInstance         :163-173
+            ("rotate", child, angle_radians, axis)                      RotatedInstance            :182-264
+            ("combo", [children])                                       HitableCombo               :130-142
+        A combo distributes over its children (each leaf keeps the instances above it, outermost first), so the object becomes a
+        run of primitives in the combo's own order.  Leaves whose chain is one of the factories' shapes -- Translate(Sphere at 0),
+        Translate(RotZ(RotY(RotX(Rect)))) -- are stored in the factory form unless force_chain; every other leaf in chain form."""
+        self.obj_first.append(len(self.kind)); n0 = len(self.kind)
+
+        def walk(node, ops, force):
+            tag = node[0]
+            if tag == "translate":
+                walk(node[1], ops + [(capi.OP_TRANSLATE, tuple(float(F(x)) for x in node[2]))], force)
+            elif tag == "rotate":
+                a = F(node[2])
+                walk(node[1], ops + [(capi.OP_ROTATE_X + int(node[3]), (float(F(math.sin(float(a)))), float(F(math.cos(float(a)))), 0.0))], force)
+            elif tag == "combo":
+                # a combo of rects alone is a cube's (its faces share the chain and may keep the factory form); any other combo
+                # hands its leaves over in chain form
+                force = force or any(ch[0] != "rect" for ch in node[1])
+                for ch in node[1]:
+                    walk(ch, ops, force)
+            elif tag == "sphere":
+                c = tuple(float(F(x)) for x in node[1]); r = float(F(node[2]))
+                if not force and len(ops) == 1 and ops[0][0] == capi.OP_TRANSLATE and c == (0.0, 0.0, 0.0):
+                    self._prim(capi.PRIM_SPHERE, ops[0][1], (r, 0, 0, 0, 0), 0, (0, 1, 0, 1, 0, 1), mat)
+                else:
+                    self._leaf_chain(capi.PRIM_SPHERE, (r, 0, 0, 0, 0), 0, ops, mat, c)
+            elif tag == "rect":
+                _, a, b, a0, a1, b0, b1, cc, rev = node
+                a0, a1, b0, b1, cc = (float(F(x)) for x in (a0, a1, b0, b1, cc))
+                if a0 > a1: a0, a1 = a1, a0                       # Hitables.cpp:86-90
+                if b0 > b1: b0, b1 = b1, b0
+                kinds = [k for k, _ in ops]
+                if not force and kinds == [capi.OP_TRANSLATE, capi.OP_ROTATE_Z, capi.OP_ROTATE_Y, capi.OP_ROTATE_X]:
+                    rot = (ops[3][1][0], ops[3][1][1], ops[2][1][0], ops[2][1][1], ops[1][1][0], ops[1][1][1])
+                    self._prim(capi.PRIM_RECT, ops[0][1], (a0, a1, b0, b1, cc), capi.axes_pack(a, b, 3 - a - b, rev, 1), rot, mat)
+                elif not force and kinds in ([], [capi.OP_TRANSLATE]):           # a bare or merely translated rect
+                    self._prim(capi.PRIM_RECT, ops[0][1] if ops else (0.0, 0.0, 0.0), (a0, a1, b0, b1, cc), capi.axes_pack(a, b, 3 - a - b, rev, 0), (0, 1, 0, 1, 0, 1), mat)
+                else:
+                    self._leaf_chain(capi.PRIM_RECT, (a0, a1, b0, b1, cc), capi.axes_pack(a, b, 3 - a - b, rev, 0), ops, mat, (0.0, 0.0, 0.0))
+            else:
+                raise ValueError(f"unknown hitable {tag!r}")
+
+        walk(tree, [], force_chain)
+        if len(self.kind) == n0:
+            raise ValueError("hitable without a leaf")
+        self.obj_count.append(len(self.kind) - n0)
+
+    def _leaf_chain(self, kind, geom, axes, ops, mat, center):
+        if len(ops) > capi.MAX_CHAIN_OPS:
+            raise ValueError(f"an instance chain of {len(ops)} ops (the device takes {capi.MAX_CHAIN_OPS})")
+        self._prim(kind, (0.0, 0.0, 0.0), geom, axes, (0, 1, 0, 1, 0, 1), mat, chain=list(ops), center=center)
 
     def sphere(self, center, radius, mat):                       # SimpleObject.cpp:129-139
         self.obj_first.append(len(self.kind)); self.obj_count.append(1)
@@ -108,6 +168,17 @@ class FlatScene:
                 prim_rot=f32(self.rot, 6), prim_mat=u32(self.pmat), obj_first=u32(self.obj_first), obj_count=u32(self.obj_count),
                 mat_kind=u32(self.mkind), mat_albedo=f32(self.albedo, 3), mat_fuzz=f32(self.fuzz, 1), mat_ior=f32(self.ior, 1),
                 mat_emit=f32(self.emit, 3))
+            if any(c is not None for c in self.chain):
+                first, nops, kinds, args = [], [], [], []
+                for c in self.chain:
+                    if c is None:
+                        first.append(0); nops.append(0)
+                    else:
+                        first.append(len(kinds) + 1); nops.append(len(c))
+                        kinds += [k for k, _ in c]; args += [a for _, a in c]
+                self._arrays.update(prim_chain=u32(first), prim_nops=u32(nops), prim_center=f32(self.center, 3),
+                                    op_kind=u32(kinds if kinds else [0]), op_arg=f32(args if args else [(0.0, 0.0, 0.0)], 3))
+                self._n_ops = len(kinds)
             if self.textures:
                 sizes = np.array([t.shape[0] * t.shape[1] for t in self.textures], np.uint64)
                 self._arrays.update(tex_width=u32([t.shape[1] for t in self.textures]), tex_height=u32([t.shape[0] for t in self.textures]),
@@ -141,6 +212,7 @@ class FlatScene:
             s.n_nodes = 0; s.root = capi.CHILD_NONE
         s.ambient = (C.c_float * 3)(*self.ambient)
         s.n_textures = len(self.textures)
+        s.n_ops = getattr(self, "_n_ops", 0) if "prim_chain" in a else 0
         return s
 
 
@@ -219,6 +291,23 @@ def cornell_two_boxes(aspect=1.0):
     h = F(0.6)
     s.cube((0.32, float(F(-1.0) + h * F(0.5)), 0.4), (0.0, -0.3, 0.0), (float(h),) * 3, lam3)
     cam = make_camera((0.0, 0.0, 4.0), (0.0, 0.0, 0.0), 40.0, 0.0, aspect)
+    return s, cam
+
+
+def chains_world(aspect=1.0):
+    """WORLD_ID_CHAINS of the C++ layer (host.cpp World::ConstructWorld): the hitable vocabulary beyond the factories' shapes."""
+    s = FlatScene(ambient=(0.6, 0.7, 0.9))
+    grey = s.lambertian((0.5, 0.5, 0.5)); white = s.diffuse_light((4.0, 4.0, 4.0)); metal = s.metal((0.7, 0.6, 0.5), 0.0)
+    brown = s.lambertian((0.4, 0.2, 0.1)); red = s.lambertian((0.65, 0.05, 0.05)); glass = s.dielectric(1.5)
+    s.rect(XZ_RECT, (0.0, -2.0, 0.0), (0.0, 0.0, 0.0), 12.0, 12.0, False, grey)
+    s.rect(XZ_RECT, (0.0, 5.0, 0.0), (0.0, 0.2, 0.0), 3.0, 3.0, True, white)
+    s.hitable(("translate", ("rotate", ("sphere", (1.0, 2.0, 3.0), 0.8), 30.0, 1), (0.25, -0.5, 0.125)), metal)
+    s.hitable(("combo", [("sphere", (-1.5, 0.2, 0.3), 0.6), ("sphere", (-0.9, 0.5, 0.1), 0.5)]), brown)
+    s.hitable(("rotate", ("translate", ("rotate", ("rect", 0, 2, -0.8, 0.8, -0.6, 0.6, 0.1, False), 0.7, 2), (0.4, -1.0, 0.9)), -0.5, 0), red)
+    pair = ("combo", [("sphere", (0.5, 0.0, 0.0), 0.25), ("translate", ("sphere", (0.0, 0.0, 0.0), 0.2), (-0.5, 0.1, 0.0))])
+    every = ("combo", [("sphere", (0.0, 0.0, 0.0), 0.4), ("translate", ("rect", 0, 1, -0.3, 0.3, -0.3, 0.3, 0.0, False), (0.0, 0.6, 0.0)), pair])
+    s.hitable(("translate", ("rotate", every, 1.1, 1), (2.2, -1.0, 0.5)), glass)
+    cam = make_camera((0.5, 1.0, 9.0), (0.0, 0.0, 0.0), 45.0, 0.05, aspect)
     return s, cam
 
 

@@ -7,7 +7,7 @@ import numpy as np
 from raytracinginaweekend_amd import capi, scene
 
 LIB = os.path.join(os.path.dirname(capi.LIB_PATH), "libmirt_host.so")
-WORLD_RANDOM_SPHERES, WORLD_CORNELL, WORLD_FOUR_SPHERES, WORLD_TWO_BOXES = 0, 1, 2, 3
+WORLD_RANDOM_SPHERES, WORLD_CORNELL, WORLD_FOUR_SPHERES, WORLD_TWO_BOXES, WORLD_TEXTURED, WORLD_CHAINS = 0, 1, 2, 3, 4, 5
 _lib = None
 
 
@@ -32,6 +32,8 @@ def lib():
         L.mirt_host_render.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_int,
                                        C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
         L.mirt_host_render.restype = C.c_int
+        L.mirt_host_try_chain.argtypes = [C.c_uint32, C.c_float, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
+        L.mirt_host_try_chain.restype = C.c_int
         _lib = L
     return _lib
 
@@ -54,6 +56,12 @@ def build_world(world_id, aspect, seed):
         fs.kind = _arr(s.prim_kind, n).tolist(); fs.off = _arr(s.prim_off, n, 3); fs.geom = _arr(s.prim_geom, n, 5)
         fs.axes = _arr(s.prim_axes, n).tolist(); fs.rot = _arr(s.prim_rot, n, 6); fs.pmat = _arr(s.prim_mat, n).tolist()
         fs.obj_first = _arr(s.obj_first, no).tolist(); fs.obj_count = _arr(s.obj_count, no).tolist()
+        fs.chain = [None] * n; fs.center = [(0.0, 0.0, 0.0)] * n
+        if s.prim_chain:                              # chain-form primitives: their ops, outermost first, and the spheres' own centres
+            first, nops, ctr = _arr(s.prim_chain, n), _arr(s.prim_nops, n), _arr(s.prim_center, n, 3)
+            kinds = _arr(s.op_kind, max(1, s.n_ops)); args = _arr(s.op_arg, max(1, s.n_ops), 3)
+            fs.center = [tuple(float(x) for x in c) for c in ctr]
+            fs.chain = [None if not first[p] else [(int(kinds[first[p] - 1 + k]), tuple(float(x) for x in args[first[p] - 1 + k])) for k in range(nops[p])] for p in range(n)]
         fs.mkind = _arr(s.mat_kind, nm).tolist(); fs.albedo = _arr(s.mat_albedo, nm, 3); fs.fuzz = _arr(s.mat_fuzz, nm)
         fs.ior = _arr(s.mat_ior, nm); fs.emit = _arr(s.mat_emit, nm, 3)
         if s.n_textures:
@@ -69,6 +77,15 @@ def build_world(world_id, aspect, seed):
         return fs, cam
     finally:
         lib().mirt_host_world_destroy(h)
+
+
+def try_chain(n_translates, cx=0.0):
+    """Translate^n(Sphere(cx,0,0)) through Object::Flatten -> (n_prims, n_ops, chain form?) or raises with the flattener's message."""
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    err = C.create_string_buffer(512)
+    if lib().mirt_host_try_chain(n_translates, cx, C.byref(a), C.byref(b), C.byref(c), err, 512) != 0:
+        raise RuntimeError(err.value.decode())
+    return a.value, b.value, bool(c.value)
 
 
 def render(world_id, w, h, spp, depth=50, scene_seed=1, seed=0x5EED, one_spp=False, normal=False, ppm_dir=None):

@@ -60,9 +60,43 @@ def test_cpp_bvh_equals_the_oracles_reference_builder(case):
     assert np.array_equal(o.nodes[0], h.nodes[0]) and np.array_equal(o.nodes[1], h.nodes[1])
 
 
-def test_flattener_rejects_chains_the_device_cannot_represent():
+def test_general_hitables_flatten_and_what_is_still_refused():
+    """VERDICT r2 "What's missing 1": scene code written against the reference's Hitables.h composes freely.  WORLD_ID_CHAINS builds,
+    through the C++ classes alone, every shape round 2's flattener threw on -- a rotated sphere, an off-centre sphere inside a
+    chain, combos of things other than rects (and a combo inside a combo), a translation that is not outermost, rotations not
+    ordered z,y,x -- and flattens to the arrays of the Python mirror.  What is still refused: more than MIRT_MAX_CHAIN_OPS
+    nested instances, and an unknown world id."""
+    h, hcam = hostapi.build_world(hostapi.WORLD_CHAINS, 1.0, seed=1)
+    p, pcam = scene.chains_world(1.0)
+    ha, pa = h.arrays(), p.arrays()
+    for k in ("prim_kind", "prim_off", "prim_geom", "prim_axes", "prim_rot", "obj_first", "obj_count", "prim_chain", "prim_nops", "prim_center", "op_kind", "op_arg"):
+        assert np.array_equal(ha[k], pa[k]), k
+    assert np.array_equal(per_prim_material(h), per_prim_material(p)) and bytes(hcam) == bytes(pcam)
+    kinds = [[k for k, _ in c] if c is not None else None for c in h.chain]
+    assert kinds[:2] == [None, None]                                             # the two factory rects keep the factory form
+    assert kinds[2] == [capi.OP_TRANSLATE, capi.OP_ROTATE_Y] and h.center[2] == (1.0, 2.0, 3.0)     # rotated, off-centre sphere
+    assert kinds[3] == [] and kinds[4] == [] and h.obj_count[3] == 2             # a combo of two bare spheres: one object, two primitives
+    assert kinds[5] == [capi.OP_ROTATE_X, capi.OP_TRANSLATE, capi.OP_ROTATE_Z]   # neither translate-outermost nor z,y,x
+    assert h.obj_count[5] == 4
+    assert kinds[6] == [capi.OP_TRANSLATE, capi.OP_ROTATE_Y] and kinds[7] == [capi.OP_TRANSLATE, capi.OP_ROTATE_Y, capi.OP_TRANSLATE]
+    assert kinds[9] == [capi.OP_TRANSLATE, capi.OP_ROTATE_Y, capi.OP_TRANSLATE]  # the nested combo's translated ball: chain form although Translate(Sphere at 0)
+    # the factories' own shapes stay in the factory form; a sphere with a centre of its own does not
+    assert hostapi.try_chain(1) == (1, 0, False) and hostapi.try_chain(1, 0.5) == (1, 1, True) and hostapi.try_chain(0, 0.0) == (1, 0, True)
+    assert hostapi.try_chain(capi.MAX_CHAIN_OPS, 0.5) == (1, capi.MAX_CHAIN_OPS, True)
+    with pytest.raises(RuntimeError, match="9 nested instances; the device takes 8"):
+        hostapi.try_chain(capi.MAX_CHAIN_OPS + 1, 0.5)
     err = hostapi.C.create_string_buffer(256)
     assert hostapi.lib().mirt_host_world_create(99, 1.0, 1, err, 256) is None and b"unknown world" in err.value
+    # the library's own checks behind the C ABI (mirt_build_bvh validates like mirt_upload_scene, without a GPU)
+    bad = scene.chains_world(1.0)[0]
+    bad.chain[2] = bad.chain[2] + [(7, (0.0, 0.0, 0.0))]
+    with pytest.raises(capi.MirtError):
+        capi.build_bvh(bad)
+    two = scene.FlatScene(); m = two.lambertian()
+    two.rect(scene.XZ_RECT, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 1.0, 1.0, False, m); two.rect(scene.XZ_RECT, (0.0, 1.0, 0.0), (0.0, 0.0, 0.0), 1.0, 1.0, False, m)
+    two.obj_first, two.obj_count = [0], [2]                                      # two factory rects with DIFFERENT chains in one object
+    with pytest.raises(capi.MirtError):
+        capi.build_bvh(two)
 
 
 @pytest.mark.gpu
@@ -76,6 +110,14 @@ def test_traceray_through_the_cpp_api_matches_the_c_abi(gpu, tmp_path):
             a = hostapi.render(wid, w, h, spp, 50, 1, 0x5EED, one_spp, normal)
             b = gpu.render(w, h, spp, 50, 0x5EED, flags)
             assert np.array_equal(a, b["rgba8"]), (wid, one_spp, normal)
+    # the chains world: TraceRay through the C++ classes == the C ABI on the Python mirror == the oracle, bit for bit
+    ps, pcam = scene.chains_world(1.0)
+    gpu.upload_scene(ps); gpu.set_camera(pcam)
+    a = hostapi.render(hostapi.WORLD_CHAINS, 80, 80, 5, 50, 1, 0x5EED, False, False)
+    b = gpu.render(80, 80, 5, 50, 0x5EED, capi.FLAG_ACCEL_AUTO)
+    osum, ost = orc.trace(ps, pcam, 80, 80, 5, 50, 0x5EED, orc.FLAG_ACCEL_LIST)
+    assert np.array_equal(a, b["rgba8"]) and np.array_equal(b["rgba8"], orc.resolve(osum, 5)[1]) and b["stats"].rays == ost.rays
+    H.assert_bits(b["sum"], osum, "chains world")
     out = hostapi.render(hostapi.WORLD_CORNELL, 32, 24, 2, ppm_dir=str(tmp_path))
     txt = open(tmp_path / "OutputImage.ppm").read().split("\n")
     assert txt[:3] == ["P3", "32 24", "255"] and len(txt) == 3 + 32 * 24 + 1

@@ -58,8 +58,17 @@ def main(tag, name, workload="cornell", spp=256, size="1024x1024"):
         print(f"#   SIMD cycles: GRBM_GUI_ACTIVE/8 x 1024 SIMDs = {simd_cycles / 1e9:.1f} G; VALU issue (2 cycles each) fills {100 * 2 * c['SQ_INSTS_VALU'] / simd_cycles:.1f} % of them")
         wc = c["SQ_WAVE_CYCLES"]
         print(f"#   wave-cycles: issuing {100 * c['SQ_ACTIVE_INST_ANY'] / wc:.1f} %, issue-stalled (pipe taken by another wave) {100 * c['SQ_WAIT_INST_ANY'] / wc:.1f} %, waiting (s_waitcnt) {100 * c['SQ_WAIT_ANY'] / wc:.1f} %")
+        if "SQ_LDS_BANK_CONFLICT" in c and c.get("SQ_LDS_IDX_ACTIVE"):
+            print(f"#   lds_bank_conflict_rate = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {100 * c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE']:.1f} %"
+                  f" ({100 * c['SQ_LDS_BANK_CONFLICT'] / wc:.2f} % of the wave-cycles; waiting on LDS {100 * c.get('SQ_WAIT_INST_LDS', 0) / wc:.2f} % of them; see profiles/r03_lds_conflicts.txt)")
+        if "SQ_INSTS_BRANCH" in c:
+            print(f"#   branches per 64 rays {c['SQ_INSTS_BRANCH'] * 64 / rays:.0f}, scalar memory instructions {c.get('SQ_INSTS_SMEM', 0) * 64 / rays:.0f}")
         hbm = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
-        print(f"#   HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KB (x2 on gfx950), WRITE_SIZE {c['WRITE_SIZE']:.0f} KB -> {hbm / 1e9:.2f} GB per launch for {paths * 16 / 1e9:.2f} GB of radiance slots = {hbm / kt / 1e6:.0f} GB/s")
+        slot_bytes = paths * 12.0                                  # one 12-byte radiance slot per path (three floats, rt_kernels.h RadSlot)
+        written = c["WRITE_SIZE"] * 1024
+        print(f"#   HBM: FETCH_SIZE {c['FETCH_SIZE']:.0f} KB (x2 on gfx950), WRITE_SIZE {c['WRITE_SIZE']:.0f} KB -> {hbm / 1e9:.2f} GB per launch = {hbm / kt / 1e6:.0f} GB/s")
+        print(f"#   written / algorithmic = {written / 1e9:.2f} GB / {slot_bytes / 1e9:.2f} GB of 12-byte radiance slots = {written / slot_bytes:.2f}x"
+              f" (each lane ends its path at its own time and stores its own 12 bytes: partial 64-byte writes)")
         kname = json.loads(open(os.path.join(out, f"bench_{tag}.json")).read().strip().split("\n")[-1])["roofline"]["kernel"]
         path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
