@@ -22,8 +22,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-Wall", "-Wno-unused-function", "-Wno-bitwise-instead-of-logical", "-ldl", "-pthread"]
 
 
+def skip_variant() -> bool:
+    """MIRT_SKIP_VARIANT=1: build the product library alone (the measured-and-lost second-stream variant is test material)."""
+    return os.environ.get("MIRT_SKIP_VARIANT", "") not in ("", "0")
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(VARIANT_LIB):
+    if not os.path.exists(LIB) or (not skip_variant() and not os.path.exists(VARIANT_LIB)):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
@@ -41,7 +46,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     variant = [hipcc] + FLAGS + ["-DMIRT_DEFER_MD=1", "-DMIRT_LIST_WAVES=6"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", VARIANT_LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
-    procs = [subprocess.Popen(cmd), subprocess.Popen(variant)]
+    procs = [subprocess.Popen(cmd)] + ([] if skip_variant() else [subprocess.Popen(variant)])
     if any([p.wait() != 0 for p in procs]):
         raise subprocess.CalledProcessError(1, cmd)
     build_host(verbose)

@@ -15,7 +15,18 @@
 // Either way the image differs from the one-device image only by the re-association of the per-pixel sum.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+// librccl is opened with dlopen, so a host without it (or without its headers) still builds and runs the single-GPU product and
+// the peer reduce: the header is used when it is there, else the handful of declarations the four entry points need (values
+// as in rccl.h / nccl.h, checked against the header by the static_asserts below whenever it is present)
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+static_assert(ncclSuccess == 0 && ncclFloat32 == 7 && ncclSum == 0, "the local declarations below must follow rccl.h");
+#else
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 #include <chrono>
 #include <cstring>
 #include <mutex>
@@ -82,6 +93,7 @@ struct mirt_multi {
     float *d_pixels = nullptr; uint8_t *d_rgba = nullptr;
     size_t n_floats = 0;                      // capacity of the buffers above
     int reduce_want = MIRT_REDUCE_AUTO, reduce_used = 0;
+    bool auto_peer = false;                   // MIRT_REDUCE_AUTO found that RCCL cannot set up its communicators here: the peer reduce from then on
     bool distinct = true;
     mirt_multi_info last{};
     std::string err;
@@ -214,7 +226,6 @@ static int ensure_buffers(mirt_multi *m, size_t n_floats, size_t npix)
         MCHK(m, hipMalloc((void **)&m->d_sum[i], n_floats * sizeof(float)));
     }
     MCHK(m, hipSetDevice(m->dev[0]));
-    for (size_t i = 1; i < n; ++i) MCHK(m, hipMalloc((void **)&m->d_stage[i], n_floats * sizeof(float)));
     MCHK(m, hipMalloc((void **)&m->d_pixels, n_floats * sizeof(float)));
     MCHK(m, hipMalloc((void **)&m->d_rgba, npix * 4));
     m->n_floats = n_floats;
@@ -225,6 +236,8 @@ static int reduce_peer(mirt_multi *m, size_t n_floats, const std::vector<bool> &
 {
     MCHK(m, hipSetDevice(m->dev[0]));
     const size_t n = m->dev.size(), bytes = n_floats * sizeof(float);
+    for (size_t i = 1; i < n; ++i)                                         // staging buffers on device 0, only when this path runs (RCCL needs none)
+        if (has[i] && !m->d_stage[i]) MCHK(m, hipMalloc((void **)&m->d_stage[i], m->n_floats * sizeof(float)));
     for (size_t i = 1; i < n; ++i) {
         if (!has[i]) continue;
         MCHK(m, hipMemcpyPeerAsync(m->d_stage[i], m->dev[0], m->d_sum[i], m->dev[i], bytes, m->copy_stream[i]));
@@ -241,14 +254,19 @@ static int reduce_peer(mirt_multi *m, size_t n_floats, const std::vector<bool> &
     return MIRT_OK;
 }
 
+// the communicators, once per mirt_multi; nothing has touched the sums when this fails
+static int rccl_init(mirt_multi *m)
+{
+    const size_t n = m->dev.size();
+    if (!m->comm.empty()) return MIRT_OK;
+    m->comm.assign(n, nullptr);
+    ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), (int)n, m->dev.data());
+    if (r != ncclSuccess) { m->comm.clear(); return mfail(m, MIRT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
+    return MIRT_OK;
+}
 static int reduce_rccl(mirt_multi *m, size_t n_floats)
 {
     const size_t n = m->dev.size();
-    if (m->comm.empty()) {
-        m->comm.assign(n, nullptr);
-        ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), (int)n, m->dev.data());
-        if (r != ncclSuccess) { m->comm.clear(); return mfail(m, MIRT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r)); }
-    }
     ncclResult_t r = g_rccl.GroupStart();
     for (size_t i = 0; i < n && r == ncclSuccess; ++i) {
         (void)hipSetDevice(m->dev[i]);
@@ -303,8 +321,14 @@ extern "C" int mirt_multi_render(mirt_multi *m, const mirt_render_params *p, flo
     if (n > 1 || m->reduce_want == MIRT_REDUCE_RCCL) {                     // RCCL asked for by name also runs with one device (a one-rank reduce)
         const bool want_rccl = m->reduce_want == MIRT_REDUCE_RCCL || (m->reduce_want == MIRT_REDUCE_AUTO && m->distinct);
         if (want_rccl && !m->distinct) return mfail(m, MIRT_ERR_ARG, "mirt_multi_render: RCCL needs distinct devices (a device is listed twice); use MIRT_REDUCE_PEER");
-        if (want_rccl && g_rccl.load()) used = MIRT_REDUCE_RCCL;
+        if (want_rccl && !m->auto_peer && g_rccl.load()) used = MIRT_REDUCE_RCCL;
         else if (m->reduce_want == MIRT_REDUCE_RCCL) { const char *why = dlerror(); return mfail(m, MIRT_ERR_STATE, std::string("mirt_multi_render: cannot load librccl.so: ") + (why ? why : "missing symbols")); }
+        if (used == MIRT_REDUCE_RCCL && (rc = rccl_init(m)) != MIRT_OK) {
+            // AUTO promised "RCCL ..., else PEER": a library that loads but cannot build its communicators here (no usable
+            // transport between these devices, say) is the "else"; remembered, so later renders do not try again
+            if (m->reduce_want != MIRT_REDUCE_AUTO) return rc;
+            m->auto_peer = true; used = MIRT_REDUCE_PEER; m->err.clear();
+        }
         rc = used == MIRT_REDUCE_RCCL ? reduce_rccl(m, n_floats) : reduce_peer(m, n_floats, has);
         if (rc) return rc;
     }

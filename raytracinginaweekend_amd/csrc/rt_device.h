@@ -354,13 +354,14 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
         if (disc > 0) {                                                  // one exit, flags instead of early returns
             // The second root is tried when the first is out of [t_min, t_max] (Hitables.cpp:31-41), and it is never smaller than
             // the first: it can only be accepted when the first fell below t_min.  Which side of t_min the first root lies on is
-            // decided by an estimate of its quotient wherever that is safe (within 3e-7 of it, the band around t_min is 1e-5 wide),
+            // decided by an estimate of its quotient wherever that is safe (within 3e-7 of it, the band around t_min is 1e-5 |t_min| wide),
             // so one IEEE divide runs instead of two; inside the band (or with a NaN) both run as written.  closest_list's
             // deferred roots do the same.
             const float sq = MIRT_SQRT(disc), two_a = 2.0f * a;
             const float n1 = -b - sq, n2 = -b + sq;
             const float q1 = n1 * __builtin_amdgcn_rcpf(two_a);
-            const bool first = q1 > t_min * 1.00001f, second = q1 < t_min * 0.99999f;
+            const float band = 0.00001f * __builtin_fabsf(t_min);                 // around t_min of either sign (the test hooks take any t_min)
+            const bool first = q1 > t_min + band, second = q1 < t_min - band;
             float t = (first ? n1 : n2) / two_a;
             in = (t <= t_max) & (t >= t_min);
             if (!(first | second)) {

@@ -21,6 +21,13 @@ class Hip:
         self.rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         self.rt.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.rt.hipFree.argtypes = [C.c_void_p]
+        self.rt.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes(self):
+        assert self.rt.hipDeviceSynchronize() == 0
+        f, t = C.c_size_t(), C.c_size_t()
+        assert self.rt.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
 
     def zeros(self, nbytes):
         p = C.c_void_p()
@@ -64,6 +71,24 @@ def test_noalloc_matches_render_device():
         for fl in (capi.FLAG_ACCEL_AUTO, 0):
             a, b = _both(ctx, hip, 120, 80, 4, fl)
             assert a.any() and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        # ... and no device memory is taken by a call: free bytes before and after a (warmed) call are the same, on the list walk, on
+        # the BVH walks (whose kernels use a few dwords of private scratch per lane: the runtime sizes that at their first launch,
+        # which the calls above were) and on an image of more than 2 Mi pixels, i.e. several pixel tiles of the fixed scratch
+        big_w, big_h = 2048, 1200                               # 2.46 Mi pixels > the 2 Mi paths of one batch
+        outs = {k: hip.zeros(n) for k, n in (("small", 120 * 80 * 12), ("big", big_w * big_h * 12))}
+        ref_big = hip.zeros(big_w * big_h * 12)
+        for fl in (capi.FLAG_ACCEL_AUTO, 0):
+            ctx.render_device_noalloc(capi.RenderParams(big_w, big_h, 0, 1, 50, fl, 9), outs["big"], None)     # warm: first launch of this size
+        ctx.render_device(capi.RenderParams(big_w, big_h, 0, 2, 50, capi.FLAG_ACCEL_AUTO, 9), ref_big, None, capi.Stats())
+        assert hip.rt.hipMemset(outs["big"], 0, big_w * big_h * 12) == 0
+        before = hip.free_bytes()
+        ctx.render_device_noalloc(capi.RenderParams(120, 80, 0, 4, 50, capi.FLAG_ACCEL_AUTO, 9), outs["small"], None)
+        ctx.render_device_noalloc(capi.RenderParams(120, 80, 4, 4, 50, 0, 9), outs["small"], None)
+        ctx.render_device_noalloc(capi.RenderParams(big_w, big_h, 0, 2, 50, capi.FLAG_ACCEL_AUTO, 9), outs["big"], None)
+        assert hip.free_bytes() == before, "mirt_render_device_noalloc took device memory"
+        a, b = hip.fetch(ref_big, (big_h, big_w, 3)), hip.fetch(outs["big"], (big_h, big_w, 3))
+        assert a.any() and np.array_equal(a.view(np.uint32), b.view(np.uint32))       # two pixel tiles, same bits
+        hip.fetch(outs["small"], (80, 120, 3))
         # beyond the fixed scratch: a clear error, not an allocation
         p = capi.RenderParams(4096, 4096, 0, 1024, 50, capi.FLAG_ACCEL_AUTO, 1)
         d = hip.zeros(64)
