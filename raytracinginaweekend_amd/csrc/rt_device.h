@@ -152,6 +152,65 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// The same block in two steps.  The counter is (c0, c1, c2, c3) = (pixel, sample, stage, iteration): round 1's products
+// depend on (c0, c2) alone and c3 enters by one xor; of round 2's products one depends on round 1's first word, which the
+// iteration has not reached yet, and so does one of round 3's.  The blocks of one (pixel, sample, stage) over many
+// iterations therefore share up to 4 of their 20 multiplications: philox_head makes them once, philox_tail finishes a
+// block for an iteration (rt_kernels.h coop_draws: the owner of a pending draw publishes its head).
+// SHARE: 1 = round 1 shared (two products, four words), 2 = and round 2's (three, four words), 3 = and round 3's (four
+// products, five words).
+template <int SHARE> struct PhiloxHead { uint32_t w[SHARE >= 3 ? 5 : 4]; };
+template <int SHARE>
+__device__ __forceinline__ PhiloxHead<SHARE> philox_head(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t k0, uint32_t k1)
+{
+    static_assert(SHARE >= 1 && SHARE <= 3, "rounds that can be shared");
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;                    // round 1
+    const uint32_t A = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c1, k0, 0x96), D = (uint32_t)p0;
+    PhiloxHead<SHARE> hd;
+    hd.w[1] = (uint32_t)(p0 >> 32) ^ k1;                                // round 1's third word, before the iteration is xored in
+    if constexpr (SHARE == 1) { hd.w[0] = (uint32_t)p1; hd.w[2] = A; hd.w[3] = D; }
+    else {
+        hd.w[0] = (uint32_t)p1 ^ (k0 + W0);                             // round 1's second word with round 2's key
+        const uint64_t q0 = (uint64_t)0xD2511F53u * A;                  // round 2, the product that does not see the iteration
+        const uint32_t E = __builtin_amdgcn_bitop3_b32((uint32_t)(q0 >> 32), D, k1 + W1, 0x96);
+        if constexpr (SHARE == 2) { hd.w[2] = E; hd.w[3] = (uint32_t)q0; }
+        else {
+            const uint64_t q1 = (uint64_t)0xCD9E8D57u * E;              // round 3, likewise
+            hd.w[2] = (uint32_t)q0 ^ (k1 + 2u * W1); hd.w[3] = (uint32_t)q1;
+            hd.w[4] = (uint32_t)(q1 >> 32) ^ (k0 + 2u * W0);
+        }
+    }
+    return hd;
+}
+template <int SHARE>
+__device__ __forceinline__ void philox_tail(const PhiloxHead<SHARE> &hd, uint32_t it, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    uint32_t c0, c1, c2, c3;
+    if constexpr (SHARE == 1) { c0 = hd.w[2]; c1 = hd.w[0]; c2 = hd.w[1] ^ it; c3 = hd.w[3]; }
+    else {
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * (hd.w[1] ^ it);     // round 2's other product
+        const uint32_t x0 = (uint32_t)(p1 >> 32) ^ hd.w[0], x1 = (uint32_t)p1;
+        if constexpr (SHARE == 2) { c0 = x0; c1 = x1; c2 = hd.w[2]; c3 = hd.w[3]; }
+        else {
+            const uint64_t p0 = (uint64_t)0xD2511F53u * x0;             // round 3's other product
+            c0 = hd.w[4] ^ x1; c1 = hd.w[3]; c2 = (uint32_t)(p0 >> 32) ^ hd.w[2]; c3 = (uint32_t)p0;
+        }
+    }
+    k0 += (uint32_t)SHARE * W0; k1 += (uint32_t)SHARE * W1;
+#pragma unroll
+    for (int r = SHARE; r < 10; ++r) {
+        uint64_t m0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t m1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(m1 >> 32), c1, k0, 0x96);
+        uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(m0 >> 32), c3, k1, 0x96);
+        c1 = (uint32_t)m1; c3 = (uint32_t)m0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 // Randomizer.h:9-17 with (min,max) = (0,1): (float)((double)raw / 2^32).  u32 -> f32 conversion
 // rounds to nearest-even exactly like double -> float of the exact quotient, and the power-of-two
 // scale is exact, so no f64 is needed.  Can return 1.0f for raw >= 2^32-128, as the reference can.

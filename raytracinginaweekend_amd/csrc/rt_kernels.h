@@ -671,7 +671,15 @@ __device__ __forceinline__ uint32_t rank_in(unsigned long long m)
 // round 0 the still-pending lanes publish their keys in LDS and ALL 64 lanes evaluate candidates for
 // them: with n pending, each gets G = pow2 <= 64/n consecutive iterations in one round.  The owner
 // takes the first accepted iteration, exactly the one its own loop would have stopped at.
-struct CoopLds { uint32_t pix[64], smp[64], it[64], stg[64]; };
+// SHARE > 0: the owner publishes the head of its Philox blocks (rt_device.h philox_head: the rounds that are the same for
+// every iteration, which it has from its own block 0) instead of the key, and the helpers finish the block for their
+// iteration: 2, 3 or 4 of a block's 20 multiplications less per candidate, for four or five head words kept by every lane
+// through the rounds.  The list kernels take it (MIRT_LIST_SHARE); the BVH kernels, compiled for 64 registers, spill on it.
+// `it` in bytes (iterations stay below MIRT_REJECT_CAP + 8): the list kernel's seven workgroups per CU leave ~1.6 KB of LDS a
+// workgroup for the scene's primitives and materials, which the two-box Cornell scene needs.
+template <int SHARE> struct CoopLdsT { uint32_t w[SHARE == 0 ? 3 : (SHARE == 3 ? 5 : 4)][64]; uint8_t it[64]; };
+static_assert(MIRT_REJECT_CAP + 8 <= 256, "CoopLdsT::it is a byte");
+typedef CoopLdsT<0> CoopLds;
 
 // Is the candidate (the first three words of a Philox block) inside the unit sphere?  The reference decides on
 // the mapped floats (Randomizer.h:43-46: reject while dot(p,p) >= 1), and mapping three words costs 21 f64
@@ -697,16 +705,19 @@ __device__ __forceinline__ bool candidate_inside(const uint32_t r[4])
 
 // need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this).
 // LSTAGE: the stage (1 + depth) differs from lane to lane (k_trace) and travels with the key.
-template <bool LSTAGE>
-__device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t need, uint32_t pixel, uint32_t sample,
+template <bool LSTAGE, int SHARE = 0>
+__device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, uint32_t need, uint32_t pixel, uint32_t sample,
                                            uint32_t stage, uint32_t k0, uint32_t k1, f3 &sphere_pt, float &unorm)
 {
+    constexpr int HS = SHARE == 0 ? 1 : SHARE;                  // (PhiloxHead<0> does not exist)
     bool pending = false;
     uint32_t next_it = 1;
     uint32_t w0 = 0, w1 = 0, w2 = 0;                            // the accepted candidate's raw words
+    PhiloxHead<HS> head = {};
     if (need != NEED_NONE) {                                    // round 0: block 0 serves all three materials
         uint32_t r[4];
-        philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
+        if constexpr (SHARE != 0) { head = philox_head<HS>(pixel, sample, stage, k0, k1); philox_tail<HS>(head, 0u, k0, k1, r); }
+        else philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
         unorm = map_unorm(r[0]);
         w0 = r[0]; w1 = r[1]; w2 = r[2];                       // read only when need == NEED_SPHERE
         pending = (need == NEED_SPHERE) & !candidate_inside(r) & !(MIRT_TEXP & 4);
@@ -717,16 +728,27 @@ __device__ __forceinline__ void coop_draws(CoopLds &cl, uint32_t lane, uint32_t 
         const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per pending lane
         const uint32_t G = 1u << lg;
         const uint32_t rank = rank_in(mask);
-        if (pending) { cl.pix[rank] = pixel; cl.smp[rank] = sample; cl.it[rank] = next_it; if (LSTAGE) cl.stg[rank] = stage; }
+        if (pending) {
+            cl.it[rank] = (uint8_t)next_it;
+            if constexpr (SHARE != 0) {
+#pragma unroll
+                for (int i = 0; i < (SHARE == 3 ? 5 : 4); ++i) cl.w[i][rank] = head.w[i];
+            } else { cl.w[0][rank] = pixel; cl.w[1][rank] = sample; if (LSTAGE) cl.w[2][rank] = stage; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t e = lane >> lg, sub = lane & (G - 1u);
         uint32_t r[4] = { 0u, 0u, 0u, 0u };
         bool acc = false;
-        const uint32_t it = cl.it[e] + sub;                       // e < 64 always; entries >= n are stale and unused
+        const uint32_t it = (uint32_t)cl.it[e] + sub;             // e < 64 always; entries >= n are stale and unused
         if ((e < n) & (it < MIRT_REJECT_CAP)) {
-            philox4x32_10(cl.pix[e], cl.smp[e], LSTAGE ? cl.stg[e] : stage, it, k0, k1, r);
+            if constexpr (SHARE != 0) {
+                PhiloxHead<HS> hh;
+#pragma unroll
+                for (int i = 0; i < (SHARE == 3 ? 5 : 4); ++i) hh.w[i] = cl.w[i][e];
+                philox_tail<HS>(hh, it, k0, k1, r);
+            } else philox4x32_10(cl.w[0][e], cl.w[1][e], LSTAGE ? cl.w[2][e] : stage, it, k0, k1, r);
             acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
         }
         const unsigned long long am = __ballot(acc);
@@ -943,6 +965,12 @@ __device__ __forceinline__ void wave_lds_sync()
 #ifndef MIRT_LIST_STASH
 #define MIRT_LIST_STASH 128u
 #endif
+#ifndef MIRT_LIST_SHARE
+#define MIRT_LIST_SHARE 2         // Philox rounds the helpers of a cooperative draw take from the owner (coop_draws): list kernel
+#endif
+#ifndef MIRT_BVH_SHARE
+#define MIRT_BVH_SHARE 0          // ... BVH kernels (spills under their 64-register cap: profiles/r03_trace_ablation.txt)
+#endif
 #ifndef MIRT_LIST_WAVES
 #define MIRT_LIST_WAVES 7
 #endif
@@ -965,7 +993,8 @@ template <int ACCEL, bool PLDS, bool FULL>
 __device__ __forceinline__ void trace_body(const TraceArgs &a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ CoopLds s_coop[MIRT_BLOCK / 64];
+    constexpr int SHARE = ACCEL == 0 ? MIRT_LIST_SHARE : MIRT_BVH_SHARE;
+    __shared__ CoopLdsT<SHARE> s_coop[MIRT_BLOCK / 64];
     constexpr bool BIG_STASH = ACCEL == 0;
     constexpr uint32_t STASH_N = BIG_STASH ? MIRT_LIST_STASH : 64u;
     __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
@@ -1209,7 +1238,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         }
         // ---- phase 2 (whole wave): the draws of Scatter, keyed by each lane's own depth
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
-        coop_draws<true>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
+        coop_draws<true, SHARE>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
         // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         bool parked = false, retry = false;
         if constexpr (DEFER) {
@@ -1803,7 +1832,15 @@ __global__ void k_philox_batch(const uint32_t *ctr, uint32_t n, uint32_t k0, uin
     if (i >= n) return;
     uint32_t r[4];
     philox4x32_10(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], ctr[4 * i + 3], k0, k1, r);
-    out[4 * i] = r[0]; out[4 * i + 1] = r[1]; out[4 * i + 2] = r[2]; out[4 * i + 3] = r[3];
+    // the head/tail forms coop_draws uses must give the same block at every level of sharing: a difference inverts the words,
+    // which the caller's comparison with the known answers then reports
+    uint32_t s1[4], s2[4], s3[4], bad = 0u;
+    philox_tail<1>(philox_head<1>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], k0, k1), ctr[4 * i + 3], k0, k1, s1);
+    philox_tail<2>(philox_head<2>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], k0, k1), ctr[4 * i + 3], k0, k1, s2);
+    philox_tail<3>(philox_head<3>(ctr[4 * i], ctr[4 * i + 1], ctr[4 * i + 2], k0, k1), ctr[4 * i + 3], k0, k1, s3);
+    for (int k = 0; k < 4; ++k) bad |= (s1[k] ^ r[k]) | (s2[k] ^ r[k]) | (s3[k] ^ r[k]);
+    const uint32_t flip = bad ? 0xFFFFFFFFu : 0u;
+    out[4 * i] = r[0] ^ flip; out[4 * i + 1] = r[1] ^ flip; out[4 * i + 2] = r[2] ^ flip; out[4 * i + 3] = r[3] ^ flip;
 }
 
 // arithmetic self-test: op 0 a/b, 1 sqrt(a), 2 pow5f(a), 3 map_unorm(bits a), 4 map_pm1(bits a),

@@ -6,11 +6,13 @@ from raytracinginaweekend_amd import capi, scene
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 world = sys.argv[2] if len(sys.argv) > 2 else "cornell"
-w, h = (1024, 1024) if world == "cornell" else (1200, 800)
+w, h = (1024, 1024) if world.startswith("cornell") else (1200, 800)
 if os.environ.get("MIRT_SIZE"):
     w, h = (int(x) for x in os.environ["MIRT_SIZE"].split("x"))
 if world == "cornell":
     s, cam = scene.cornell_box(1.0)
+elif world == "cornell2":                     # the reference's Cornell box with its two rotated boxes (18 primitives)
+    s, cam = scene.cornell_two_boxes(1.0)
 elif world == "textured":                     # two 1024^2 image textures (4 MB each) on floor, wall and ball
     from tests import helpers as H
     s, cam = scene.textured_world(w / h, H.synthetic_texture(1024, 1024, 1, "ramp"), H.synthetic_texture(1024, 1024, 2, "checker"))
