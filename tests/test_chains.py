@@ -8,6 +8,8 @@ GPU half: the device against the oracle, bit for bit -- per primitive, through t
 visiting orders, and as images."""
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -239,7 +241,7 @@ def _gpu_scene(seed, n=10):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", range(1, 1 + int(os.environ.get("MIRT_CHAIN_SEEDS", "3"))))      # a longer campaign: MIRT_CHAIN_SEEDS=100
 def test_gpu_chain_prims_and_walks(gpu, orc, seed):
     s, cam = _gpu_scene(seed)
     gpu.upload_scene(s)
