@@ -284,6 +284,27 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
             if (list_class(prims[p]) == cls) { lprims.push_back(prims[p]); lprims.back().mat = p; }
         if (cls < 4) lend[cls] = (uint32_t)lprims.size();
     }
+    // Facing pairs (rt_kernels.h rect_pair): in each orientation class the rects with the lowest and the highest plane move to the
+    // front of the class's run, low one first.  The plane is k + offset along the normal; which two are picked decides only how
+    // often the merged test applies, never a result (the kernel checks "between" per ray in the test's own arithmetic).
+    uint32_t pair_mask = 0;
+    for (uint32_t cls = 0; cls < 3; ++cls) {
+        const uint32_t first = cls ? lend[cls - 1] : 0u, end = lend[cls];
+        if (end - first < 2u) continue;
+        const uint32_t cax = cls == 0 ? 2u : (cls == 1 ? 1u : 0u);
+        auto plane = [&](uint32_t i) { return (double)lprims[i].gb[1] + (double)lprims[i].off[cax]; };
+        uint32_t lo = first, hi = first;
+        for (uint32_t i = first; i < end; ++i) { if (plane(i) < plane(lo)) lo = i; if (plane(i) > plane(hi)) hi = i; }
+        if (!(plane(lo) < plane(hi))) continue;                       // all in one plane (or NaN): no pair
+        std::swap(lprims[first], lprims[lo]);
+        if (hi == first) hi = lo;                                      // the high one was sitting where the low one went
+        std::swap(lprims[first + 1], lprims[hi]);
+        pair_mask |= 1u << cls;
+        // what rect_pair reads of both, in rotation words that unrotated records do not use (rot[2..5] = the record's last 16 bytes)
+        PrimRec &a = lprims[first], &b = lprims[first + 1];
+        a.rot[2] = a.gb[1]; a.rot[3] = a.off[cax]; a.rot[4] = b.gb[1]; a.rot[5] = b.off[cax];
+        memcpy(&b.rot[2], &a.mat, 4); memcpy(&b.rot[3], &b.mat, 4);
+    }
     std::vector<NodeRec> nodes(tree.box.size());
     for (size_t i = 0; i < nodes.size(); ++i) {
         for (int a = 0; a < 3; ++a) { nodes[i].mn[a] = tree.box[i].mn[a]; nodes[i].mx[a] = tree.box[i].mx[a]; }
@@ -352,6 +373,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
         const PrimRec &r = lprims[i];
         if (!(std::fabs(r.gb[1]) <= 0x1p38f && std::fabs(r.off[0]) <= 0x1p38f && std::fabs(r.off[1]) <= 0x1p38f && std::fabs(r.off[2]) <= 0x1p38f)) d.list_fast = 0u;
     }
+    if (d.list_fast) d.list_fast |= pair_mask << 1;
     d.nodes = (const NodeRec *)c->d_nodes.p; d.n_nodes = (uint32_t)nodes.size();
     d.nodes2 = (const Node2 *)c->d_nodes2.p; d.single = single ? 1u : 0u;
     d.objs = (const uint2 *)c->d_objs.p; d.n_objects = s->n_objects;

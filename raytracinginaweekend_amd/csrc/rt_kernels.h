@@ -52,7 +52,8 @@ __device__ __forceinline__ void store_rad(RadSlot *rad, size_t slot, f3 v)
 struct SceneDev {
     const PrimRec *prims;  uint32_t n_prims;
     const PrimRec *lprims; uint32_t lend[4];     // the list walk's copy, sorted by class (closest_list); .mat = index in `prims`
-    uint32_t list_fast;                           // every unrotated rect has |plane|, |offset| <= 2^38: rect_run may share its divisions
+    uint32_t list_fast;                           // bit 0: every unrotated rect has |plane|, |offset| <= 2^38: rect_loop may share its divisions;
+                                                  // bits 1-3: orientation class 0-2 starts with a facing pair (rect_pair)
     const NodeRec *nodes;  uint32_t n_nodes;     // the tree as given (or built), walked in the reference's order
     const Node2   *nodes2;                        // same tree, child boxes in the parent, walked near-first
     uint32_t node_bytes;                          // size of the node record the launch stages in LDS (32 or 64)
@@ -112,6 +113,9 @@ struct BounceArgs {
 // closest primitives collided -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 16 % in k_trace on the Cornell box (9 primitives:
 // three triples/pairs share banks).  With one 16-byte chunk of padding per record (20 banks) the first 16 records start on 16
 // different bank groups.  -DMIRT_LDS_PRIM_STRIDE=64 restores the old layout for the A/B (profiles/r03_lds_conflicts.txt).
+#ifndef MIRT_RECT_PAIRS
+#define MIRT_RECT_PAIRS 1         // facing pairs of rects tested as one (rect_pair)
+#endif
 #ifndef MIRT_LDS_PRIM_STRIDE
 #define MIRT_LDS_PRIM_STRIDE 80u
 #endif
@@ -194,6 +198,48 @@ struct Prims {
 //    does not depend on t_max (the second root is never smaller than the first).
 typedef uint32_t ListWord4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) ListWord4 *ListPtr;   // records of the sorted list, read through the scalar cache
+// A facing pair: the lowest and the highest plane of an orientation class (Cornell's left and right wall, its floor and ceiling).
+// A ray whose origin lies between the two planes can only meet the one ahead of it: for the other, t = (k - origin.c) / direction.c
+// is negative or zero and fails t >= t_min.  When that holds for every lane of the wave, ONE test serves both rects: each lane
+// takes the record of the rect ahead from the workgroup's LDS copy (a per-lane index, where the class loop reads wave-uniform
+// records through the scalar cache) and runs the very arithmetic of rect_loop on it; the numerators, which decide "behind",
+// are computed as rect_loop computes them, so the argument holds in float arithmetic and not just on paper.  Otherwise
+// (some lane outside the slab and heading in, or a NaN) nothing happens here and the class loop tests both as usual.  FAST path
+// only: direction.c is then non-zero and t_min >= 2^-19 > 0.
+// The pair's records come first in their class's run of the sorted list, low plane first; the upload leaves what this function
+// needs of both in their unused rotation words: (k, offset.c) of the low and of the high one in the first record, the two scene
+// indices in the second.
+template <int A, int B, int C, bool PLDS>
+__device__ __forceinline__ void rect_pair(const Prims<PLDS> &P, const DivBy &by_dc, ListPtr &q, uint32_t &p, f3 o, f3 d,
+                                          float t_min, float &t_max, int32_t &best)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x4 pf = q[3];
+    const u32x2 pi = *(const __attribute__((address_space(4))) u32x2 *)(q + 7);
+    const float oc = C == 0 ? o.x : (C == 1 ? o.y : o.z), dc = C == 0 ? d.x : (C == 1 ? d.y : d.z);
+    const float num_lo = __uint_as_float(pf.x) - (oc - __uint_as_float(pf.y)), num_hi = __uint_as_float(pf.z) - (oc - __uint_as_float(pf.w));
+    // the rect behind the ray must fail t >= t_min for sure: its numerator has the sign that makes t <= 0, or -- an origin ON a
+    // wall lands an ulp to either side of it -- is at most half of t_min * |direction.c| (division is monotone, so t <= ~t_min / 2)
+    const bool fwd = dc > 0.0f;
+    const bool behind_misses = (fwd ? num_lo : -num_hi) <= (0.5f * t_min) * __builtin_fabsf(dc);
+    if (__ballot(!behind_misses) != 0ull) return;
+    const int32_t idx = fwd ? (int32_t)pi.y : (int32_t)pi.x;
+    const float num = fwd ? num_hi : num_lo;
+    const PrimRec &r = P[(uint32_t)idx];
+    const float da = A == 0 ? d.x : (A == 1 ? d.y : d.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
+    const float oa = (A == 0 ? o.x : (A == 1 ? o.y : o.z)) - r.off[A], ob = (B == 0 ? o.x : (B == 1 ? o.y : o.z)) - r.off[B];
+    const float t = div_by(by_dc, num);
+    const float a = oa + t * da;
+    const float b = ob + t * db;
+    const bool in_t = (t >= t_min) & ((t < t_max) | ((t == t_max) & (idx > best)));
+    const bool in_ab = (a >= r.ga[0]) & (a <= r.ga[1]) & (b >= r.ga[2]) & (b <= r.gb[0]);
+    const bool hit = in_t & in_ab;
+    t_max = hit ? t : t_max;
+    best = hit ? idx : best;
+    p += 2; q += 8;
+}
+
 // One class of the sorted list: unrotated rects whose axis triple is (A, B, C).  Branch-free on purpose: with 64
 // unrelated rays some lane always passes the t test, so skipping a/b buys nothing and the selects keep the loop
 // free of phi copies.  pr.mat of the sorted copy holds the primitive's index in the scene's own order.
@@ -201,9 +247,9 @@ typedef const __attribute__((address_space(4))) ListWord4 *ListPtr;   // records
 // IEEE divide because every rect of the class divides by the same direction.c.  closest_list takes it when the whole wave
 // is inside div_by's operand range (see there); a numerator too small for its promise gives |t| < 2^-19 <= t_min
 // either way, so the rect is missed by both forms.
-template <int A, int B, int C, bool FAST>
+template <int A, int B, int C, bool FAST, bool PLDS = false>
 __device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end, f3 o, f3 d,
-                                          float t_min, float &t_max, int32_t &best)
+                                          float t_min, float &t_max, int32_t &best, const SceneDev *sc = nullptr, const Prims<PLDS> *P = nullptr)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -211,6 +257,10 @@ __device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end,
     const float da = A == 0 ? d.x : (A == 1 ? d.y : d.z), db = B == 0 ? d.x : (B == 1 ? d.y : d.z);
     if (p >= end) return;
     const DivBy by_dc = div_prepare(dc);
+    if constexpr (FAST && PLDS && MIRT_RECT_PAIRS) {
+        constexpr int CLS = C == 2 ? 0 : (C == 1 ? 1 : 2);
+        if (sc->list_fast & (2u << CLS)) rect_pair<A, B, C, PLDS>(*P, by_dc, q, p, o, d, t_min, t_max, best);
+    }
     for (; p < end; ++p, q += 4) {                                          // one running record pointer through all the class loops
         const u32x4 q0 = q[0], q1 = q[1];
         const u32x2 q2 = *(const __attribute__((address_space(4))) u32x2 *)(q + 2);
@@ -248,11 +298,12 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         const float d_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
         const float d_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
         const float o_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
-        const bool fast = (sc.list_fast != 0u) & (t_min >= 0x1p-19f) & (d_hi <= 0x1p20f) & (d_lo >= 0x1p-20f) & (o_hi <= 0x1p38f);
+        const bool fast = ((sc.list_fast & 1u) != 0u) & (t_min >= 0x1p-19f) & (d_hi <= 0x1p20f) & (d_lo >= 0x1p-20f) & (o_hi <= 0x1p38f);
         if (__ballot(!fast) == 0ull) {
-            rect_loop<0, 1, 2, true>(q, p, sc.lend[0], o, d, t_min, t_max, best);
-            rect_loop<0, 2, 1, true>(q, p, sc.lend[1], o, d, t_min, t_max, best);
-            rect_loop<2, 1, 0, true>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+            const Prims<PLDS> P(sc, v);
+            rect_loop<0, 1, 2, true, PLDS>(q, p, sc.lend[0], o, d, t_min, t_max, best, &sc, &P);
+            rect_loop<0, 2, 1, true, PLDS>(q, p, sc.lend[1], o, d, t_min, t_max, best, &sc, &P);
+            rect_loop<2, 1, 0, true, PLDS>(q, p, sc.lend[2], o, d, t_min, t_max, best, &sc, &P);
         } else {
             rect_loop<0, 1, 2, false>(q, p, sc.lend[0], o, d, t_min, t_max, best);
             rect_loop<0, 2, 1, false>(q, p, sc.lend[1], o, d, t_min, t_max, best);
@@ -1352,7 +1403,7 @@ __device__ __forceinline__ void closest_list2(const SceneDev &sc, const LdsView 
     uint32_t p = 0;
     ListPtr q = (ListPtr)sc.lprims;
     if (sc.lend[2] != 0u) {
-        bool fast = (sc.list_fast != 0u) & (t_min >= 0x1p-19f);
+        bool fast = ((sc.list_fast & 1u) != 0u) & (t_min >= 0x1p-19f);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {                                        // closest_list's range test, both rays
             const float d_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[k].x), __builtin_fabsf(d[k].y)), __builtin_fabsf(d[k].z));

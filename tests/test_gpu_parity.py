@@ -549,6 +549,55 @@ def test_axis_parallel_rays(gpu, orc, world):
     assert differs.sum() <= 8 and np.array_equal(g["t"].view(np.uint32)[differs], o["t"].view(np.uint32)[differs]) and (g["t"][differs] < o1["t"][differs]).all()
 
 
+def test_facing_rect_pairs(gpu, orc):
+    """closest_list tests the lowest and the highest plane of an orientation class as ONE rect when every ray of a wave starts
+    between them (rt_kernels.h rect_pair).  A room with a pair in each of the three orientations, more rects between the pairs,
+    a partition that does not span the room and two balls; ray origins inside the room, exactly on every plane, one float to
+    either side of every plane, and outside the room heading in -- in runs of 64 of a kind, so that whole waves take the merged
+    test, and shuffled, so that waves mix them and fall back.  Hit records against the oracle's list walk, and an image."""
+    s = scene.FlatScene(ambient=(0.2, 0.3, 0.4))
+    grey, red, lamp, glass = s.lambertian((0.6, 0.6, 0.6)), s.lambertian((0.7, 0.2, 0.2)), s.diffuse_light((6.0, 6.0, 6.0)), s.dielectric(1.5)
+    z = (0.0, 0.0, 0.0)
+    walls = [(scene.ZY_RECT, (2.0, 0.0, 0.0), True), (scene.ZY_RECT, (-1.5, 0.0, 0.0), False),       # x pair (not symmetric)
+             (scene.XZ_RECT, (0.0, 1.25, 0.0), True), (scene.XZ_RECT, (0.0, -1.0, 0.0), False),      # y pair
+             (scene.XY_RECT, (0.0, 0.0, -2.0), False), (scene.XY_RECT, (0.0, 0.0, 1.75), True)]      # z pair
+    for axes, c, rev in walls:
+        s.rect(axes, c, z, 6.0, 6.0, rev, grey)
+    s.rect(scene.XZ_RECT, (0.0, 1.2, 0.0), z, 1.0, 1.0, True, lamp)                                   # a third plane in the y class
+    s.rect(scene.ZY_RECT, (0.5, -0.25, 0.0), z, 1.0, 1.5, False, red)                                 # a partition inside the x pair
+    s.rect(scene.XY_RECT, (0.25, 0.0, 0.0), z, 1.5, 1.0, False, red)
+    s.sphere((-0.7, -0.6, 0.3), 0.4, glass); s.sphere((1.2, -0.7, -0.8), 0.3, grey)
+    capi.build_bvh(s)
+    gpu.upload_scene(s)
+    rng = np.random.default_rng(123)
+    n = 64 * 96
+    planes = {0: (-1.5, 2.0, 0.5), 1: (-1.0, 1.25, 1.2), 2: (-2.0, 1.75, 0.0)}
+    org = rng.uniform(-0.95, 0.95, (n, 3)).astype(np.float32) * np.float32([1.4, 0.9, 1.6])
+    d = rng.standard_normal((n, 3)).astype(np.float32)
+    kind = (np.arange(n) // 64) % 6                                # runs of 64: inside, on a plane, an ulp outside, an ulp inside, outside heading in, outside
+    for i in range(n):
+        ax = int(rng.integers(0, 3)); pl = np.float32(planes[ax][int(rng.integers(0, 3))])
+        if kind[i] == 1: org[i, ax] = pl
+        elif kind[i] == 2: org[i, ax] = np.nextafter(pl, np.float32(np.inf) if pl > 0 else np.float32(-np.inf))
+        elif kind[i] == 3: org[i, ax] = np.nextafter(pl, np.float32(0.0))
+        elif kind[i] >= 4:
+            org[i, ax] = np.float32(pl * rng.uniform(1.5, 4.0)) if pl != 0 else np.float32(5.0)
+            if kind[i] == 4: d[i, ax] = -np.sign(org[i, ax]) * abs(d[i, ax])
+    for tag, order in (("runs of a kind", np.arange(n)), ("shuffled", rng.permutation(n))):
+        o, _ = orc.world_hit_batch(s, org[order], d[order], 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST)
+        assert (o["prim"] >= 0).mean() > 0.7 and len(set(o["prim"].tolist())) >= 11
+        H.assert_hits_equal(gpu.world_hit_batch(org[order], d[order], 0.001, FLT_MAX, capi.FLAG_ACCEL_LIST), o, f"facing pairs, {tag}", scene=s)
+    # a t_min of either size: 2^-19 is the least the shared-division path (and with it the merged test) accepts
+    for t_min in (2.0 ** -19, 2.0 ** -21, 0.25):
+        o, _ = orc.world_hit_batch(s, org, d, t_min, 50.0, capi.FLAG_ACCEL_LIST)
+        H.assert_hits_equal(gpu.world_hit_batch(org, d, t_min, 50.0, capi.FLAG_ACCEL_LIST), o, f"facing pairs, t_min {t_min}", scene=s)
+    cam = scene.make_camera((1.2, 0.4, 1.5), (-0.4, -0.3, -0.6), 70.0, 0.05, 1.5)
+    gpu.set_camera(cam)
+    osum, ost = orc.trace(s, cam, 96, 64, 8, 50, 77, orc.FLAG_ACCEL_LIST)
+    g = gpu.render(96, 64, 8, 50, 77, capi.FLAG_ACCEL_LIST)
+    H.assert_bits(g["sum"], osum, "room image"); assert g["stats"].rays == ost.rays and ost.rays > 4 * 96 * 64 * 8
+
+
 def test_million_spheres(gpu, orc):
     """BASELINE config 4 (the generator of World.cpp:36-58 extended to a 1000x1000 grid, ~1M spheres): the host-built
     SAH tree is walked in the reference's order and near-first by the oracle and by the device (bit-exact hits and images,
