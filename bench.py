@@ -123,14 +123,24 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        warm = torch.zeros(1, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(warm)                        # creates the communicator here, not inside a timed step (--warmup 0)
-        dist.reduce(warm, dst=0)
-        torch.cuda.synchronize(dev)
+        # librccl prints a version banner on STDOUT when its first communicator comes up; stdout is for the one JSON line, so file
+        # descriptor 1 points at stderr until the communicator exists
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            warm = torch.zeros(1, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(warm)                    # creates the communicator here, not inside a timed step (--warmup 0)
+            dist.reduce(warm, dst=0)
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
         sharding.passed_first_barrier()              # tells a self-started launcher that the process group came up
 
     label, W0, H0, SPP0, cpu_spp0, bound = WORKLOADS[args.workload]
