@@ -1908,7 +1908,7 @@ __global__ void k_arith(uint32_t op, const float *x, const float *y, uint32_t n,
     case 2: r = pow5f(a); break;
     case 3: r = map_unorm(__float_as_uint(a)); break;
     case 4: r = map_pm1(__float_as_uint(a)); break;
-    case 5: r = div_by(div_prepare(b), a); break;                        // the shared-denominator division of rect_run, raw
+    case 5: r = div_by(div_prepare(b), a); break;                        // the shared-denominator division of rect_loop, raw
     case 6: r = (div_den_ok(b) & div_num_ok(a)) ? 1.0f : 0.0f; break;       // inside the operand range where 5 promises the bits of a / b
     case 7: r = sqrt_wave(a); break;                                      // the render kernels' square root (lean form per wave, rt_device.h)
     case 9: r = __uint_as_float(fast_div(__float_as_uint(a), fastdiv_make(__float_as_uint(b)))); break;   // path id / (pixels of a batch, image width)
