@@ -1064,6 +1064,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     uint32_t own_k = 0;                     // chunks of its own the wave has started
     uint32_t x_made = 0, x_iters = 0;       // MIRT_TEXP & 16: per-wave schedule dump (tools/wave_dump.py)
     const unsigned long long x_t0 = (MIRT_TEXP & 16) ? wall_clock64() : 0ull;
+    const unsigned long long x_c0 = (MIRT_TEXP & 64) ? __builtin_readcyclecounter() : 0ull;   // MIRT_TEXP 16 + 64: the dump carries shader-clock cycles instead of the hardware ids
     // the next run of path ids for this wave (w_next == w_end): its next own chunk, else a claim; false when the batch is handed out
     auto next_range = [&]() -> bool {
         if (own_k < a.own_chunks) {
@@ -1333,6 +1334,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     if ((MIRT_TEXP & 16) && a.mdq && lane == 0) {
         const unsigned long long t1 = wall_clock64();
         const uint32_t gw = blockIdx.x * (MIRT_BLOCK / 64) + wave;
+        const unsigned long long x_c = (MIRT_TEXP & 64) ? __builtin_readcyclecounter() - x_c0 : 0ull;
+        if (MIRT_TEXP & 64) a.mdq[2 * gw] = make_float4(__uint_as_float(x_made), __uint_as_float(x_iters), __uint_as_float((uint32_t)x_c), __uint_as_float((uint32_t)(x_c >> 32)));
+        else
         a.mdq[2 * gw] = make_float4(__uint_as_float(x_made), __uint_as_float(x_iters), __uint_as_float(__builtin_amdgcn_s_getreg(63492)), __uint_as_float(__builtin_amdgcn_s_getreg(63508)));
         a.mdq[2 * gw + 1] = make_float4(__uint_as_float((uint32_t)x_t0), __uint_as_float((uint32_t)(x_t0 >> 32)), __uint_as_float((uint32_t)t1), __uint_as_float((uint32_t)(t1 >> 32)));
     }
