@@ -89,19 +89,20 @@ float orc_map_minmax2(uint32_t raw, float mn, float mx)
     r = r * (double)(mx - mn) + (double)mn;
     return (float)r;
 }
-/* The device computes raw/4294967295.0 without a divide: q0 = raw*R, q = fma(fma(-q0, D, raw), R, q0)
- * with R = 1/D correctly rounded (Markstein).  Returns the number of raw values in [begin,end]
- * (inclusive) for which that differs from the IEEE quotient. */
-uint64_t orc_check_div_u32max(uint32_t begin, uint32_t end)
+/* The device maps a word to (-1,1) without the divide: (float)fma(raw * R, 2.0, -1.0) with R = 1/4294967295.0 correctly
+ * rounded.  raw * R can be one ulp off the IEEE quotient, but that bit never reaches the float.  Returns the number of raw
+ * values in [begin,end] (inclusive) for which the short form differs from orc_map_minmax2(raw, -1, 1), the reference's form. */
+uint64_t orc_check_pm1_short(uint32_t begin, uint32_t end)
 {
-    const double D = 4294967295.0, R = 1.0 / 4294967295.0;
+    const double R = 1.0 / 4294967295.0;
     uint64_t bad = 0;
 #pragma omp parallel for reduction(+ : bad) schedule(static)
     for (int64_t i = (int64_t)begin; i <= (int64_t)end; ++i) {
-        double a = (double)(uint32_t)i;
-        double q0 = a * R;
-        double q = fma(fma(-q0, D, a), R, q0);
-        bad += (q != a / D);
+        const uint32_t raw = (uint32_t)i;
+        const float want = orc_map_minmax2(raw, -1.0f, 1.0f);
+        const float got = (float)fma((double)raw * R, 2.0, -1.0);
+        uint32_t x, y; memcpy(&x, &want, 4); memcpy(&y, &got, 4);
+        bad += (x != y);
     }
     return bad;
 }

@@ -121,7 +121,7 @@ void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_
 float    orc_map_minmax(uint32_t raw, float mn, float mx);    /* [min,max)  :9-17  */
 float    orc_map_minmax2(uint32_t raw, float mn, float mx);   /* [min,max]  :20-26 */
 /* exhaustive self-check of the division-free form of raw/4294967295.0 used on the device */
-uint64_t orc_check_div_u32max(uint32_t begin, uint32_t end);
+uint64_t orc_check_pm1_short(uint32_t begin, uint32_t end);
 
 /* SimpleTexture2D_TGAImage::Sample, SimpleTexture2D.cpp:130-147 */
 void orc_tex_sample_batch(const orc_scene *sc, uint32_t tex, const float *uv, size_t n, float *rgb_out);

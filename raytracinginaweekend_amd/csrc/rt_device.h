@@ -5,7 +5,8 @@
 // DirectXMath SSE2 path (no FMA), and parity with the CPU oracle is bit-exact only if no
 // multiply-add is contracted.  Divisions and square roots are IEEE correctly rounded (hipcc's
 // default -fhip-fp32-correctly-rounded-divide-sqrt).  Explicit fma() calls are used only where
-// the oracle uses them too (the exact-quotient trick in map_pm1).
+// the result is proven equal to the plain form (map_pm1, checked on all 2^32 words; div_by and the lean square root, which
+// run the hardware's own sequences).
 //
 // File:line citations are relative to /root/reference/RayTracer/RayTracer/.
 #pragma once
@@ -217,16 +218,15 @@ __device__ __forceinline__ void philox_tail(const PhiloxHead<SHARE> &hd, uint32_
 __device__ __forceinline__ float map_unorm(uint32_t raw) { return (float)raw * 0x1p-32f; }
 
 // Randomizer.h:20-26 with (min,max) = (-1,1): r = raw / 4294967295.0; r = r*2.0 + (-1.0); (float)r.
-// The IEEE quotient is produced without a divide (Markstein: q0 = a*R, q = fma(fma(-q0,D,a),R,q0),
-// R = RN(1/D)); tests/test_oracle.py checks all 2^32 inputs against a true divide.  r*2.0 is exact
-// so fma(r,2,-1) rounds once, exactly as the separate multiply and add do.
+// Without the divide: q0 = raw * R with R = RN(1/4294967295.0) is the IEEE quotient or its neighbour, and that last bit of the
+// double never reaches the float: (float)fma(q0, 2.0, -1.0) equals the reference's result for every one of the 2^32 words
+// (tests/test_oracle.py walks them all against the true divide; R one ulp to either side fails for 20 and 44 of them).
+// Rounds 1 and 2 refined q0 to the exact quotient first (Markstein, two more f64 fmas) -- exact, and not needed.  r*2.0 is
+// exact, so fma(r,2,-1) rounds once, exactly as the separate multiply and add do.
 __device__ __forceinline__ float map_pm1(uint32_t raw)
 {
-    const double D = 4294967295.0, R = 1.0 / 4294967295.0;
-    double a = (double)raw;
-    double q0 = a * R;
-    double q = __builtin_fma(__builtin_fma(-q0, D, a), R, q0);
-    return (float)__builtin_fma(q, 2.0, -1.0);
+    const double R = 1.0 / 4294967295.0;
+    return (float)__builtin_fma((double)raw * R, 2.0, -1.0);
 }
 
 #define MIRT_REJECT_CAP 64   // same cap as the oracle's ORC_REJECT_CAP

@@ -41,7 +41,7 @@ def lib():
         L.orc_philox4x32_10.argtypes = [vp, vp, vp]; L.orc_philox4x32_10.restype = None
         L.orc_map_minmax.argtypes = [C.c_uint32, C.c_float, C.c_float]; L.orc_map_minmax.restype = C.c_float
         L.orc_map_minmax2.argtypes = [C.c_uint32, C.c_float, C.c_float]; L.orc_map_minmax2.restype = C.c_float
-        L.orc_check_div_u32max.argtypes = [C.c_uint32, C.c_uint32]; L.orc_check_div_u32max.restype = C.c_uint64
+        L.orc_check_pm1_short.argtypes = [C.c_uint32, C.c_uint32]; L.orc_check_pm1_short.restype = C.c_uint64
         L.orc_aabb_hit_batch.argtypes = [vp, vp, C.c_size_t, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]; L.orc_aabb_hit_batch.restype = None
         L.orc_prim_hit_batch.argtypes = [vp, C.c_uint32, vp, vp, C.c_size_t, C.c_float, C.c_float, vp]; L.orc_prim_hit_batch.restype = None
         L.orc_world_hit_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, vp, vp]; L.orc_world_hit_batch.restype = None

@@ -23,7 +23,11 @@ def test_arith_blocks(gpu, orc):
         H.assert_bits(gpu.arith_batch(1, np.abs(x)), np.sqrt(np.abs(x)).astype(np.float32), "sqrt")
         p = rng.uniform(-1.5, 1.5, 20000).astype(np.float32)
         H.assert_bits(gpu.arith_batch(2, p), (p.astype(np.float64) ** 2 * p.astype(np.float64) ** 2 * p.astype(np.float64)).astype(np.float32), "pow5")
-    raw = np.concatenate([rng.integers(0, 2 ** 32, 50000, dtype=np.uint64), [0, 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 128, 2 ** 32 - 129]]).astype(np.uint32)
+    # the words where a shortened (-1,1) mapping would go wrong first -- both ends and the zero crossing at 2^31 (rt_device.h map_pm1;
+    # the CPU test walks all 2^32 words through the same formula) -- then a random million, then the six edge words the slices below expect last
+    dense = np.concatenate([np.arange(0, 8192, dtype=np.uint64), np.arange(2 ** 31 - 8192, 2 ** 31 + 8192, dtype=np.uint64), np.arange(2 ** 32 - 8192, 2 ** 32, dtype=np.uint64)])
+    raw = np.concatenate([rng.integers(0, 2 ** 32, 50000, dtype=np.uint64), dense, rng.integers(0, 2 ** 32, 1000000, dtype=np.uint64),
+                          [0, 1, 2 ** 31, 2 ** 32 - 1, 2 ** 32 - 128, 2 ** 32 - 129]]).astype(np.uint32)
     exp0 = np.array([orc.map_minmax(r, 0.0, 1.0) for r in raw[:4000]] + [orc.map_minmax(r, 0.0, 1.0) for r in raw[-6:]], np.float32)
     exp1 = np.array([orc.map_minmax2(r, -1.0, 1.0) for r in raw[:4000]] + [orc.map_minmax2(r, -1.0, 1.0) for r in raw[-6:]], np.float32)
     sel = np.concatenate([raw[:4000], raw[-6:]])

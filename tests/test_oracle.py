@@ -44,9 +44,10 @@ def test_randomizer_mappings():
     assert orc.map_minmax(2 ** 30, 2.0, 6.0) == 3.0
 
 
-def test_division_free_quotient_is_exact_for_all_u32():
-    """The device evaluates raw/4294967295.0 with two fmas instead of a divide; all 2^32 inputs agree."""
-    assert orc.lib().orc_check_div_u32max(0, 0xFFFFFFFF) == 0
+def test_division_free_mapping_is_exact_for_all_u32():
+    """The device maps a word to (-1,1) as (float)fma(raw * RN(1/4294967295.0), 2.0, -1.0), without the reference's divide
+    (rt_device.h map_pm1); all 2^32 inputs give the reference's float."""
+    assert orc.lib().orc_check_pm1_short(0, 0xFFFFFFFF) == 0
 
 
 # ---- known answers from the reference's formulas ------------------------------------------------
