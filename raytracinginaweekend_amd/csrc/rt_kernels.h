@@ -763,8 +763,11 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
     constexpr int HS = SHARE == 0 ? 1 : SHARE;                  // (PhiloxHead<0> does not exist)
     bool pending = false;
     uint32_t next_it = 1;
-    uint32_t w0 = 0, w1 = 0, w2 = 0;                            // the accepted candidate's raw words
-    PhiloxHead<HS> head = {};
+    uint32_t w0, w1, w2;                                        // the accepted candidate's raw words: set in round 0, read only by lanes that need a sphere point
+    PhiloxHead<HS> head;                                        // likewise: published by pending lanes only (no zero fill: nine moves per pass for values nobody reads)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wuninitialized"
     if (need != NEED_NONE) {                                    // round 0: block 0 serves all three materials
         uint32_t r[4];
         if constexpr (SHARE != 0) { head = philox_head<HS>(pixel, sample, stage, k0, k1); philox_tail<HS>(head, 0u, k0, k1, r); }
@@ -818,6 +821,7 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
     }
     if (need == NEED_SPHERE) sphere_pt = mk(map_pm1(w0), map_pm1(w1), map_pm1(w2));
+#pragma clang diagnostic pop
 }
 
 // ---------------------------------------------------------------------------------- the bounce kernel
