@@ -778,8 +778,13 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
     }
     unsigned long long mask;
     while ((mask = __ballot(pending)) != 0ull) {
-        const uint32_t n = (uint32_t)__popcll(mask);
-        const uint32_t lg = n > 32 ? 0u : (n > 16 ? 1u : (n > 8 ? 2u : 3u));     // G = 1,2,4,8 iterations per pending lane
+        // n and lg are wave-uniform: counted in two 32-bit halves they stay on the scalar unit (compares of the 64-bit population
+        // count compiled to three v_cmp_*_u64 per round -- there is no scalar 64-bit less-than)
+        const uint32_t n = (uint32_t)__builtin_popcount((uint32_t)mask) + (uint32_t)__builtin_popcount((uint32_t)(mask >> 32));
+        // G = 1,2,4,8 iterations per pending lane for n > 32, > 16, > 8, <= 8: lg = 3 - clamp(ceil(log2 n) - 3, 0, 3), integer arithmetic only
+        const uint32_t cl2 = 32u - (uint32_t)__builtin_clz((n - 1u) | 1u);       // ceil(log2 n) for n >= 2 (1 for n = 1; n >= 1 here)
+        const uint32_t over = cl2 > 3u ? cl2 - 3u : 0u;
+        const uint32_t lg = 3u - (over < 3u ? over : 3u);
         const uint32_t G = 1u << lg;
         const uint32_t rank = rank_in(mask);
         if (pending) {
