@@ -608,8 +608,11 @@ __device__ __forceinline__ f3 albedo_of(const M &m, const TexRec *texs, const ui
 // and reads atten/dir only when alive, emitted only when emits -- which saves it the register moves.
 // PART: 0 the whole of Scatter; 1 without the metal/dielectric branch, 2 only that branch (the render kernel's second,
 // material-sorted stream shades those two kinds apart from the rest; the caller routes each vertex to the right part)
+// lambert_front: >= 0 when the caller already knows Lambertian's `dot(r_in.direction, rec.normal) < 0` (Materials.cpp:32) -- the
+// render kernel does: with the lazy keyed draws scatter_need asks for a sphere point exactly when that holds -- so the dot
+// product is not taken a second time (five instructions per pass); -1: evaluate it here.
 template <bool DEFAULTS = true, int PART = 0, class M>
-__device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o)
+__device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in, const f3 &pos, const f3 &nrm, f3 sphere_pt, float unorm, Scat &o, int lambert_front = -1)
 {
     if (DEFAULTS) {
         o.emitted = mk(0.0f, 0.0f, 0.0f);                               // HomemadeRayTracer.cpp:173
@@ -620,7 +623,7 @@ __device__ __forceinline__ void scatter_finish(const M &m, f3 albedo, f3 dir_in,
     uint32_t kind = m.kind;
     if ((MIRT_TEXP & 1) && kind != MIRT_MAT_DIFFUSE_LIGHT) kind = MIRT_MAT_LAMBERTIAN;
     if (PART != 2 && kind == MIRT_MAT_LAMBERTIAN) {                     // Materials.cpp:19-33
-        o.alive = dot(dir_in, nrm) < 0;
+        o.alive = lambert_front >= 0 ? lambert_front != 0 : dot(dir_in, nrm) < 0;
         o.atten = albedo;
         f3 target = (pos + nrm) + sphere_pt;
         o.dir = target - pos;

@@ -1327,7 +1327,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         if (ready && !done && !parked && !retry) {
             Scat s;
             const f3 albedo = (FULL && a.sc.n_textures != 0u) ? albedo_of(*M, a.sc.texs, a.sc.texels, h.u, h.v) : mk(M->albedo[0], M->albedo[1], M->albedo[2]);
-            scatter_finish<ACCEL != 0, DEFER ? 1 : 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s);
+            scatter_finish<ACCEL != 0, DEFER ? 1 : 0>(*M, albedo, d, h.pos, h.nrm, sp, un, s, ACCEL == 0 ? (int)(need == NEED_SPHERE) : -1);   // (the BVH kernels, at their register cap, take the dot product again)
             if (s.alive) { o = h.pos; d = s.dir; thr = thr * s.atten; }
             else { radiance = s.emits ? thr * s.emitted : scale(thr, 0.0f); done = true; }   // an absorbed path: thr * (0,0,0), :173
         }
