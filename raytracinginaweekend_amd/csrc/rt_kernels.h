@@ -298,8 +298,14 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         const float d_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
         const float d_lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y)), __builtin_fabsf(d.z));
         const float o_hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.x), __builtin_fabsf(o.y)), __builtin_fabsf(o.z));
-        const bool fast = ((sc.list_fast & 1u) != 0u) & (t_min >= 0x1p-19f) & (d_hi <= 0x1p20f) & (d_lo >= 0x1p-20f) & (o_hi <= 0x1p38f);
-        if (__ballot(!fast) == 0ull) {
+        // (the scene's and the caller's part of the condition is wave-uniform and decided on the scalar unit first: and-ed into the
+        // per-lane flag it was turned into lane masks and back -- eight vector instructions per pass)
+        bool fast_wave = false;
+        if (((sc.list_fast & 1u) != 0u) && t_min >= 0x1p-19f) {
+            // one ballot per compare (a ballot of a compare is that compare; a ballot of their conjunction costs a select and a compare more)
+            fast_wave = (__builtin_amdgcn_ballot_w64(!(d_hi <= 0x1p20f)) | __builtin_amdgcn_ballot_w64(!(d_lo >= 0x1p-20f)) | __builtin_amdgcn_ballot_w64(!(o_hi <= 0x1p38f))) == 0ull;
+        }
+        if (fast_wave) {
             const Prims<PLDS> P(sc, v);
             rect_loop<0, 1, 2, true, PLDS>(q, p, sc.lend[0], o, d, t_min, t_max, best, &sc, &P);
             rect_loop<0, 2, 1, true, PLDS>(q, p, sc.lend[1], o, d, t_min, t_max, best, &sc, &P);
@@ -344,7 +350,11 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         // when four_a * c was absorbed (disc == bb) the sphere is parked and judged by its roots as written.
         const bool behind = (b > 0.0f) & (c > 0.0f) & (disc < bb);
         const bool cross = (disc > 0) & !behind;
-        if (!(MIRT_TEXP & 32) && __ballot(cross & (p_idx >= 0)) != 0ull) resolve();   // TEXP 32 (timing only): a second crossing overwrites the parked sphere
+        // "some lane with a parked sphere crosses this one", from one ballot per compare (each is that compare's own mask; the ballot
+        // of the combined flag costs a select and a compare more per sphere)
+        const unsigned long long m_cross = __builtin_amdgcn_ballot_w64(disc > 0) &
+                                           ~(__builtin_amdgcn_ballot_w64(b > 0.0f) & __builtin_amdgcn_ballot_w64(c > 0.0f) & __builtin_amdgcn_ballot_w64(disc < bb));
+        if (!(MIRT_TEXP & 32) && (m_cross & __builtin_amdgcn_ballot_w64(p_idx >= 0)) != 0ull) resolve();   // TEXP 32 (timing only): a second crossing overwrites the parked sphere
         if (cross) { p_b = b; p_disc = disc; p_idx = (int32_t)q1.w; }
     }
     resolve();
