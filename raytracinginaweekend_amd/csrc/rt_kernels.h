@@ -249,7 +249,7 @@ __device__ __forceinline__ void rect_pair(const Prims<PLDS> &P, const DivBy &by_
 // either way, so the rect is missed by both forms.
 template <int A, int B, int C, bool FAST, bool PLDS = false>
 __device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end, f3 o, f3 d,
-                                          float t_min, float &t_max, int32_t &best, const SceneDev *sc = nullptr, const Prims<PLDS> *P = nullptr)
+                                          float t_min, float &t_max, int32_t &best, uint32_t list_fast = 0u, const Prims<PLDS> *P = nullptr)
 {
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -259,7 +259,7 @@ __device__ __forceinline__ void rect_loop(ListPtr &q, uint32_t &p, uint32_t end,
     const DivBy by_dc = div_prepare(dc);
     if constexpr (FAST && PLDS && MIRT_RECT_PAIRS) {
         constexpr int CLS = C == 2 ? 0 : (C == 1 ? 1 : 2);
-        if (sc->list_fast & (2u << CLS)) rect_pair<A, B, C, PLDS>(*P, by_dc, q, p, o, d, t_min, t_max, best);
+        if (list_fast & (2u << CLS)) rect_pair<A, B, C, PLDS>(*P, by_dc, q, p, o, d, t_min, t_max, best);
     }
     for (; p < end; ++p, q += 4) {                                          // one running record pointer through all the class loops
         const u32x4 q0 = q[0], q1 = q[1];
@@ -291,7 +291,13 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
     int32_t best = -1;
     uint32_t p = 0;
     ListPtr q = (ListPtr)sc.lprims;
-    if (sc.lend[2] != 0u) {
+    // The scene's flags and class ends are wave-uniform and loop-invariant; left to itself the compiler turns every test of them
+    // into a 64-bit lane mask ahead of the kernel's main loop, spills the masks to VGPR lanes (the scalar file is full) and reads
+    // each back with two v_readlane where it is tested -- ten vector instructions per pass.  Pinned here, they are plain 32-bit
+    // scalars tested by s_bitcmp / s_cmp at the point of use.
+    const uint32_t list_fast = sgpr_pin(sc.list_fast);
+    const uint32_t lend0 = sgpr_pin(sc.lend[0]), lend1 = sgpr_pin(sc.lend[1]), lend2 = sgpr_pin(sc.lend[2]);
+    if (lend2 != 0u) {
         // May the rect loops share their divisions (rect_loop<FAST>, div_by)?  Every lane's three direction components in
         // [2^-20, 2^20] and |k - (origin.c - offset.c)| <= 2^40: the upload vouches for |k|, |offset| <= 2^38 (list_fast), the
         // lane for its origin.  A NaN component passes the max3/min3 tests, harmlessly: both forms then give t = NaN.
@@ -301,19 +307,19 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
         // (the scene's and the caller's part of the condition is wave-uniform and decided on the scalar unit first: and-ed into the
         // per-lane flag it was turned into lane masks and back -- eight vector instructions per pass)
         bool fast_wave = false;
-        if (((sc.list_fast & 1u) != 0u) && t_min >= 0x1p-19f) {
+        if (((list_fast & 1u) != 0u) && t_min >= 0x1p-19f) {
             // one ballot per compare (a ballot of a compare is that compare; a ballot of their conjunction costs a select and a compare more)
             fast_wave = (__builtin_amdgcn_ballot_w64(!(d_hi <= 0x1p20f)) | __builtin_amdgcn_ballot_w64(!(d_lo >= 0x1p-20f)) | __builtin_amdgcn_ballot_w64(!(o_hi <= 0x1p38f))) == 0ull;
         }
         if (fast_wave) {
             const Prims<PLDS> P(sc, v);
-            rect_loop<0, 1, 2, true, PLDS>(q, p, sc.lend[0], o, d, t_min, t_max, best, &sc, &P);
-            rect_loop<0, 2, 1, true, PLDS>(q, p, sc.lend[1], o, d, t_min, t_max, best, &sc, &P);
-            rect_loop<2, 1, 0, true, PLDS>(q, p, sc.lend[2], o, d, t_min, t_max, best, &sc, &P);
+            rect_loop<0, 1, 2, true, PLDS>(q, p, lend0, o, d, t_min, t_max, best, list_fast, &P);
+            rect_loop<0, 2, 1, true, PLDS>(q, p, lend1, o, d, t_min, t_max, best, list_fast, &P);
+            rect_loop<2, 1, 0, true, PLDS>(q, p, lend2, o, d, t_min, t_max, best, list_fast, &P);
         } else {
-            rect_loop<0, 1, 2, false>(q, p, sc.lend[0], o, d, t_min, t_max, best);
-            rect_loop<0, 2, 1, false>(q, p, sc.lend[1], o, d, t_min, t_max, best);
-            rect_loop<2, 1, 0, false>(q, p, sc.lend[2], o, d, t_min, t_max, best);
+            rect_loop<0, 1, 2, false>(q, p, lend0, o, d, t_min, t_max, best);
+            rect_loop<0, 2, 1, false>(q, p, lend1, o, d, t_min, t_max, best);
+            rect_loop<2, 1, 0, false>(q, p, lend2, o, d, t_min, t_max, best);
         }
     }
 
