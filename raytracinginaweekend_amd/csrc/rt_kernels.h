@@ -755,30 +755,35 @@ typedef CoopLdsT<0> CoopLds;
 // multiply-adds, no conversions).  The mapped floats' dot product is within 2e-6 of it: outside a band of 8e-6 around 1
 // the integer decides, inside it (about one candidate in 10^5) the reference's own arithmetic does.  Only the accepted
 // candidate is mapped exactly, once, by its owner.
-__device__ __forceinline__ bool candidate_inside(const uint32_t r[4])
+// candidate_score: the squared length in units of 2^-30 with the band already decided (0 / ONE inside it), so that "inside" is
+// the plain compare score < CAND_ONE -- which a wave-wide ballot gets for nothing.
+constexpr uint32_t CAND_ONE = 0x40000000u;
+__device__ __forceinline__ uint32_t candidate_score(const uint32_t r[4])
 {
     // sum (r_i - 2^31)^2 = sum r_i^2 - 2^32 * sum r_i + 3 * 2^62, evaluated modulo 2^64 (the true value is <= 3 * 2^62, so
     // nothing is lost): unsigned multiply-adds, and the other two terms only touch the high word
     const uint64_t Q = (uint64_t)r[0] * r[0] + (uint64_t)r[1] * r[1] + (uint64_t)r[2] * r[2];
-    const uint32_t hi = (uint32_t)(Q >> 32) - (r[0] + r[1] + r[2]) + 0xC0000000u;   // squared length in units of 2^-30
-    constexpr uint32_t ONE = 0x40000000u, BAND = 8600u;                      // 8600 / 2^30 = 8.0e-6
-    bool inside = hi < ONE;
-    if (hi - (ONE - BAND) < 2u * BAND) {
+    uint32_t hi = (uint32_t)(Q >> 32) - (r[0] + r[1] + r[2]) + 0xC0000000u;   // squared length in units of 2^-30
+    constexpr uint32_t BAND = 8600u;                                         // 8600 / 2^30 = 8.0e-6
+    if (hi - (CAND_ONE - BAND) < 2u * BAND) {
         const f3 p = mk(map_pm1(r[0]), map_pm1(r[1]), map_pm1(r[2]));
-        inside = !(dot(p, p) >= 1.0f);
+        hi = !(dot(p, p) >= 1.0f) ? 0u : CAND_ONE;
     }
-    return inside;
+    return hi;
 }
+__device__ __forceinline__ bool candidate_inside(const uint32_t r[4]) { return candidate_score(r) < CAND_ONE; }
 
 // need: NEED_* of this lane (NEED_NONE for idle lanes; every lane of the wave must call this).
 // LSTAGE: the stage (1 + depth) differs from lane to lane (k_trace) and travels with the key.
-template <bool LSTAGE, int SHARE = 0>
+// ALL_EVAL: every lane finishes a block in a cooperative round, needed or not (see there); without it only the helpers do.
+template <bool LSTAGE, int SHARE = 0, bool ALL_EVAL = false>
 __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, uint32_t need, uint32_t pixel, uint32_t sample,
                                            uint32_t stage, uint32_t k0, uint32_t k1, f3 &sphere_pt, float &unorm)
 {
     constexpr int HS = SHARE == 0 ? 1 : SHARE;                  // (PhiloxHead<0> does not exist)
-    bool pending = false;
-    uint32_t next_it = 1;
+    // Wave-wide questions are asked as ballots of plain compares (a ballot of a compare is the compare's own mask; a ballot of a
+    // flag carried around the loop costs a select and a compare more): "pending" is nit != 0, "accepted" a compare of the score.
+    uint32_t nit = 0u;                                          // a pending lane's next iteration (>= 1); 0: not pending
     uint32_t w0, w1, w2;                                        // the accepted candidate's raw words: set in round 0, read only by lanes that need a sphere point
     PhiloxHead<HS> head;                                        // likewise: published by pending lanes only (no zero fill: nine moves per pass for values nobody reads)
 #pragma clang diagnostic push
@@ -790,10 +795,11 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         else philox4x32_10(pixel, sample, stage, 0, k0, k1, r);
         unorm = map_unorm(r[0]);
         w0 = r[0]; w1 = r[1]; w2 = r[2];                       // read only when need == NEED_SPHERE
-        pending = (need == NEED_SPHERE) & !candidate_inside(r) & !(MIRT_TEXP & 4);
+        nit = ((need == NEED_SPHERE) & !candidate_inside(r) & !(MIRT_TEXP & 4)) ? 1u : 0u;
     }
     unsigned long long mask;
-    while ((mask = __ballot(pending)) != 0ull) {
+    while ((mask = __builtin_amdgcn_ballot_w64(nit != 0u)) != 0ull) {
+        const bool pending = nit != 0u;
         // n and lg are wave-uniform: counted in two 32-bit halves they stay on the scalar unit (compares of the 64-bit population
         // count compiled to three v_cmp_*_u64 per round -- there is no scalar 64-bit less-than)
         const uint32_t n = (uint32_t)__builtin_popcount((uint32_t)mask) + (uint32_t)__builtin_popcount((uint32_t)(mask >> 32));
@@ -804,7 +810,7 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         const uint32_t G = 1u << lg;
         const uint32_t rank = rank_in(mask);
         if (pending) {
-            cl.it[rank] = (uint8_t)next_it;
+            cl.it[rank] = (uint8_t)nit;
             if constexpr (SHARE != 0) {
 #pragma unroll
                 for (int i = 0; i < (SHARE == 3 ? 5 : 4); ++i) cl.w[i][rank] = head.w[i];
@@ -814,19 +820,38 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint32_t e = lane >> lg, sub = lane & (G - 1u);
-        uint32_t r[4] = { 0u, 0u, 0u, 0u };
-        bool acc = false;
         const uint32_t it = (uint32_t)cl.it[e] + sub;             // e < 64 always; entries >= n are stale and unused
-        if ((e < n) & (it < MIRT_REJECT_CAP)) {
+        unsigned long long am;                                    // lanes whose candidate is accepted
+        uint32_t r[4];
+        if constexpr (ALL_EVAL) {
+            // Every lane finishes a block -- a helper for its owner's iteration, the others (e >= n: stale entries, or beyond the cap)
+            // for nobody: skipping them took a branch, a zero fill of r and a ballot of a flag, and saved nothing (the wave runs the
+            // block anyway).  Whose candidate counts is decided in the masks.  (List kernel and the sliced walk of small trees:
+            // +1.7 % / +1 %; the 1 M-sphere kernel, at its register cap, spills one more dword with it and loses 1.4 %.)
             if constexpr (SHARE != 0) {
                 PhiloxHead<HS> hh;
 #pragma unroll
                 for (int i = 0; i < (SHARE == 3 ? 5 : 4); ++i) hh.w[i] = cl.w[i][e];
                 philox_tail<HS>(hh, it, k0, k1, r);
             } else philox4x32_10(cl.w[0][e], cl.w[1][e], LSTAGE ? cl.w[2][e] : stage, it, k0, k1, r);
-            acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
+            const uint32_t score = candidate_score(r);
+            // accepted: a helper (e < n) within the cap whose candidate is inside, or the cap's last candidate, kept like the per-lane loop keeps it
+            am = __builtin_amdgcn_ballot_w64(e < n) & __builtin_amdgcn_ballot_w64(it < MIRT_REJECT_CAP) &
+                 (__builtin_amdgcn_ballot_w64(score < CAND_ONE) | __builtin_amdgcn_ballot_w64(it == MIRT_REJECT_CAP - 1u));
+        } else {
+            r[0] = r[1] = r[2] = r[3] = 0u;
+            bool acc = false;
+            if ((e < n) & (it < MIRT_REJECT_CAP)) {
+                if constexpr (SHARE != 0) {
+                    PhiloxHead<HS> hh;
+#pragma unroll
+                    for (int i = 0; i < (SHARE == 3 ? 5 : 4); ++i) hh.w[i] = cl.w[i][e];
+                    philox_tail<HS>(hh, it, k0, k1, r);
+                } else philox4x32_10(cl.w[0][e], cl.w[1][e], LSTAGE ? cl.w[2][e] : stage, it, k0, k1, r);
+                acc = candidate_inside(r) | (it == MIRT_REJECT_CAP - 1u);              // the cap keeps its last candidate, like the per-lane loop
+            }
+            am = __ballot(acc);
         }
-        const unsigned long long am = __ballot(acc);
         // a lane that is not pending can have rank == n, and n * G can be 64: its shift count is clamped (a 64-bit shift by 64 is undefined)
         const uint32_t sh = pending ? (rank << lg) : 0u;
         const uint32_t bits = (uint32_t)(am >> sh) & ((1u << G) - 1u);             // this lane's G helpers, lowest = earliest iteration
@@ -834,11 +859,10 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         // byte address of the helper lane for ds_bpermute (what __shfl computes, minus its width arithmetic); the find-first
         // of an empty set is used only under `got`
         const int src4 = (int)((got ? sh + (uint32_t)__builtin_ctz(bits) : lane) << 2);
-        next_it += (pending & !got) ? G : 0u;
+        nit = (pending & !got) ? nit + G : 0u;
         const uint32_t c0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[0]), c1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[1]),
                        c2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src4, (int)r[2]);
         w0 = got ? c0 : w0; w1 = got ? c1 : w1; w2 = got ? c2 : w2;
-        pending = pending & !got;
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
     }
     if (need == NEED_SPHERE) sphere_pt = mk(map_pm1(w0), map_pm1(w1), map_pm1(w2));
@@ -1315,7 +1339,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         }
         // ---- phase 2 (whole wave): the draws of Scatter, keyed by each lane's own depth
         f3 sp = mk(0.0f, 0.0f, 0.0f); float un = 0.0f;
-        coop_draws<true, SHARE>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
+        coop_draws<true, SHARE, ACCEL == 0 || ACCEL == 3>(s_coop[wave], lane, need, pixel, sample, 1u + depth, a.k0, a.k1, sp, un);
         // ---- phase 3 (per lane): the rest of Scatter, forward (throughput) order of :176
         bool parked = false, retry = false;
         if constexpr (DEFER) {
