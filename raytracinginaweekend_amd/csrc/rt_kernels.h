@@ -1104,7 +1104,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     const LdsView lv = lds_view(a.sc, smem);
     if (threadIdx.x < 65) s_hist[threadIdx.x] = 0;
     lds_stage(a.sc, lv);                                            // ends with a barrier
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // the wave's index is wave-uniform, and the compiler must be told: derived from threadIdx it counts as divergent, and with it
+    // the whole of the wave's bookkeeping (claimed ids, stash count) -- vector registers and vector instructions for scalar work
+    const uint32_t lane = threadIdx.x & 63u, wave = ACCEL == 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x >> 6;
     auto &stash = s_stash[wave];
 
     // wave-uniform bookkeeping
