@@ -125,6 +125,8 @@ struct LdsView {
 // A wave-uniform kernel argument made a plain SGPR value: without this the compiler re-reads arguments of a hot loop from
 // the kernarg segment in every pass (s_load + s_waitcnt in front of the node fetch) rather than keep them in registers.
 template <class T> __device__ __forceinline__ T sgpr_pin(T x) { asm volatile("" : "+s"(x)); return x; }
+// A vector register's present contents as a defined value (no instruction): for variables that only some lanes ever set and read.
+__device__ __forceinline__ uint32_t any_vgpr() { uint32_t x; asm("" : "=v"(x)); return x; }
 struct Stack {                       // one lane's traversal stack (see SceneDev::stack_lds)
     int32_t *lds, *hbm; uint32_t n_lds, stride, sp;   // capacity: tree depth + 1 levels (SceneDev::stack_depth), which no walk exceeds
     __device__ __forceinline__ Stack(const SceneDev &sc, const LdsView &v)
@@ -784,11 +786,13 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
     // Wave-wide questions are asked as ballots of plain compares (a ballot of a compare is the compare's own mask; a ballot of a
     // flag carried around the loop costs a select and a compare more): "pending" is nit != 0, "accepted" a compare of the score.
     uint32_t nit = 0u;                                          // a pending lane's next iteration (>= 1); 0: not pending
-    uint32_t w0, w1, w2;                                        // the accepted candidate's raw words: set in round 0, read only by lanes that need a sphere point
-    PhiloxHead<HS> head;                                        // likewise: published by pending lanes only (no zero fill: nine moves per pass for values nobody reads)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-#pragma clang diagnostic ignored "-Wuninitialized"
+    // The accepted candidate's raw words (set in round 0, read only by lanes that need a sphere point) and the Philox head (published
+    // by pending lanes only) start as "whatever the register holds": a zero fill is nine moves per pass for values nobody reads.
+    // (An empty asm defines them without an instruction; leaving them uninitialised would be undefined behaviour in the language.)
+    uint32_t w0 = any_vgpr(), w1 = any_vgpr(), w2 = any_vgpr();
+    PhiloxHead<HS> head;
+#pragma unroll
+    for (int i = 0; i < (HS >= 3 ? 5 : 4); ++i) head.w[i] = any_vgpr();
     if (need != NEED_NONE) {                                    // round 0: block 0 serves all three materials
         uint32_t r[4];
         if constexpr (SHARE != 0) { head = philox_head<HS>(pixel, sample, stage, k0, k1); philox_tail<HS>(head, 0u, k0, k1, r); }
@@ -866,7 +870,6 @@ __device__ __forceinline__ void coop_draws(CoopLdsT<SHARE> &cl, uint32_t lane, u
         __builtin_amdgcn_wave_barrier();                          // the LDS keys are rewritten next round
     }
     if (need == NEED_SPHERE) sphere_pt = mk(map_pm1(w0), map_pm1(w1), map_pm1(w2));
-#pragma clang diagnostic pop
 }
 
 // ---------------------------------------------------------------------------------- the bounce kernel
