@@ -229,6 +229,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     why = host::prepare_tree(*s, tree);
     if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
     if (tree.depth > 60) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: BVH deeper than 60 levels");
+    if (tree.box.size() >= (1u << 26) || s->n_objects >= (1u << 26)) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: 2^26 BVH nodes / objects or more (the walks address them by 32-bit byte offsets)");
     // From here on the context's buffers are rewritten in place (DevBuf::ensure frees before it allocates): until every
     // allocation and copy has succeeded the context has no scene, so a failed re-upload cannot leave render or batch
     // calls with pointers to freed buffers.

@@ -496,7 +496,7 @@ __device__ __forceinline__ bool leaf_prim_t(const Prims<PLDS> &P, uint32_t p, f3
 // sphere arithmetic on the same operands.
 __device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t)
 {
-    const f32x4_t r = ((GlobalF4)sph4)[p];
+    const f32x4_t r = *(GlobalF4)((const __attribute__((address_space(1))) unsigned char *)sph4 + (p << 4));   // 32-bit byte offset (fewer than 2^26 objects, as nodes)
     PrimRec pr;
     pr.off[0] = r.x; pr.off[1] = r.y; pr.off[2] = r.z; pr.info = 0u /* MIRT_PRIM_SPHERE, no rotation */; pr.ga[2] = r.w;
     return prim_t(pr, o, d, t_min, t_max, t);
@@ -519,7 +519,9 @@ __device__ __forceinline__ void fetch_node2(const Node2 *nodes2, uint32_t n_node
     c.x = pl[8 * n]; c.y = pl[9 * n]; c.z = pl[10 * n]; c.w = pl[11 * n];
     e.x = pl[12 * n]; e.y = pl[13 * n]; e.z = pl[14 * n]; e.w = pl[15 * n];
 #else
-    const GlobalF4 g = (GlobalF4)(nodes2 + cur);
+    // byte offset in 32 bits (the upload refuses trees of 2^26 nodes and more): base in SGPRs + a 32-bit lane offset is one shift
+    // per step, where the signed 64-bit index arithmetic of `nodes2 + cur` is a 64-bit shift and a 64-bit add
+    const GlobalF4 g = (GlobalF4)((const __attribute__((address_space(1))) unsigned char *)nodes2 + ((uint32_t)cur << 6));
     a = g[0]; b = g[1]; c = g[2]; e = g[3];
 #endif
 }
