@@ -190,12 +190,14 @@ int         mirt_runtime_version(int *hip_runtime, int *hip_driver);
  *                   lane, which share the passes that few lanes need (measured slower, kept under test).  Same image.
  *  "walk_yield"     near-first BVH walks in resumable slices: a wave leaves the walk loop once this many of its
  *                   lanes have finished, shades them and resumes the others (1..64); 0: every wave waits for its
- *                   longest walk; -1 (default): the library's choice, currently 56 for batches of 2 Mi paths or more, else 0.  Same image.
+ *                   longest walk; -1 (default): the library's choice, currently 52 (small trees) or 56 (trees whose top is read
+ *                   from LDS, see lds_top) for batches of 2 Mi paths or more, else 0.  Same image.
  *  "lds_top"        sliced near-first walk: this many nodes of the top of the tree are read from LDS instead of memory
  *                   (0..256; -1, default: 32 for trees of 65536 nodes and more, else 0).  Takes effect at the next
  *                   mirt_upload_scene.  Same image.
  *  "leaf_wait"      near-first BVH walks: a lane that reaches an object waits until this many lanes of its wave wait
- *                   with it (or none has a node left) before the objects are tested, all in one pass (1..64, default 4).
+ *                   with it (or none has a node left) before the objects are tested, all in one pass (1..64; -1, default: 8 for
+ *                   the sliced walk of a small tree, else 4).
  *                   Same image: a waiting lane does nothing in between.
  *  "tile_paths"     1 (default): with a BVH walk, the persistent engine hands out pixels in 8x8 tiles rather than
  *                   rows (compact patches of camera rays); 0: rows.  No effect on the image.

@@ -80,7 +80,7 @@ struct mirt_ctx {
     uint32_t paths_per_lane = 1;            // list walk: 1 = k_trace; 2 = k_trace2 (two paths in every lane share the passes few lanes need: measured 6 % slower, kept under test)
     uint32_t engine = 1;                    // 1: persistent k_trace (no path queues), 0: wavefront k_bounce per depth
     uint32_t lds_prims = 4096u;             // primitives are staged in LDS if they take no more than this; likewise
-    uint32_t leaf_wait = MIRT_LEAF_WANT;   // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2)
+    int leaf_wait = -1;                    // near-first walks: lanes waiting on a leaf that start an object-test pass (rt_kernels.h closest_bvh2); -1: by the tree's size
     int32_t lds_top = -1;                   // sliced near-first walk: top-of-tree nodes read from LDS (0..256; -1: 32 for trees of 65536 nodes and more, else 0);
                                             // takes effect at the next mirt_upload_scene
     int32_t walk_yield = -1;                // near-first walks in slices that end when this many lanes of a wave have finished;
@@ -208,7 +208,7 @@ extern "C" int mirt_set_option(mirt_ctx *c, const char *name, int64_t value)
     if (!strcmp(name, "lds_prims")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_prims out of range"); c->lds_prims = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "lds_mats")) { if (value < 0 || value > 64 * 1024) return fail(c, MIRT_ERR_ARG, "lds_mats out of range"); c->lds_mats = (uint32_t)value; return MIRT_OK; }
     if (!strcmp(name, "stack_lds")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "stack_lds out of range"); c->stack_lds = (uint32_t)value; return MIRT_OK; }
-    if (!strcmp(name, "leaf_wait")) { if (value < 1 || value > 64) return fail(c, MIRT_ERR_ARG, "leaf_wait out of range"); c->leaf_wait = (uint32_t)value; return MIRT_OK; }
+    if (!strcmp(name, "leaf_wait")) { if (value == 0 || value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "leaf_wait out of range"); c->leaf_wait = (int)value; return MIRT_OK; }
     if (!strcmp(name, "lds_top")) { if (value < -1 || value > 256) return fail(c, MIRT_ERR_ARG, "lds_top out of range"); c->lds_top = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "walk_yield")) { if (value < -1 || value > 64) return fail(c, MIRT_ERR_ARG, "walk_yield out of range"); c->walk_yield = (int32_t)value; return MIRT_OK; }
     if (!strcmp(name, "tile_paths")) { c->tile_paths = value ? 1u : 0u; return MIRT_OK; }
@@ -559,9 +559,13 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     if (fixed) cap = std::min<uint64_t>(cap, fixed->rad_paths);
     // -1 (default) = 56 for batches of 2 Mi paths or more: with the resumable walk compiled for 8 waves per SIMD like the plain
     // one (its state costs 3-4 dwords of scratch) the slices pay from ~4 M paths on (485 spheres 1200x800@500 +13 %, 1 M spheres
-    // 1920x1080@128 +10 %; 52/56/60/62 lanes: within 1 % / best / -1 % / -7 %); launches of ~1 M paths and fewer are 4 % faster plain
-    const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : ((c->walk_yield < 0 && cap >= (2ull << 20)) ? 56u : 0u);
-    if (mode == 2 && yield_want) mode = c->sc2.lds_nodes ? 4 : 3;   // the near-first walk in resumable slices (k_trace_bvh<3, ...>; <4, ...>: top of the tree from LDS)
+    // 1920x1080@128 +10 %; 52/56/60/62 lanes: within 1 % / best / -1 % / -7 %); launches of ~1 M paths and fewer are 4 % faster plain.
+    // Round 3 swept both thresholds again on the final kernels (tools/sweep_walk.sh): a small tree (no top levels in LDS), whose
+    // walk is bound by instruction issue, is 1.2 % faster with 52 finished lanes and leaf passes of 8 waiting lanes; the 1 M-sphere
+    // tree, whose walk waits on memory, is flat around 56 / 4
+    const bool small_tree = c->sc2.lds_nodes == 0;
+    const uint32_t yield_want = c->walk_yield > 0 ? (uint32_t)c->walk_yield : ((c->walk_yield < 0 && cap >= (2ull << 20)) ? (small_tree ? 52u : 56u) : 0u);
+    if (mode == 2 && yield_want) mode = small_tree ? 3 : 4;          // the near-first walk in resumable slices (k_trace_bvh<3, ...>; <4, ...>: top of the tree from LDS)
     const uint32_t npix_b = (uint32_t)std::min<uint64_t>(npix_total, cap);
     const uint32_t S = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(spp_count, cap / npix_b));
     const size_t capq = (size_t)npix_b * S;
@@ -576,7 +580,7 @@ static int render_persistent(mirt_ctx *c, const mirt_render_params *p, float *d_
     const uint32_t max_grid = (uint32_t)c->n_cu * per_cu;
     TraceArgs a{};
     a.sc = mode >= 2 ? c->sc2 : c->sc; a.cam = c->cam;
-    a.slice_want = yield_want; a.leaf_want = c->leaf_wait;
+    a.slice_want = yield_want; a.leaf_want = c->leaf_wait > 0 ? (uint32_t)c->leaf_wait : (mode == 3 ? 8u : MIRT_LEAF_WANT);
     uint32_t *counts;
     if (fixed) {
         // nothing is allocated on this path: every size is checked against the fixed scratch instead

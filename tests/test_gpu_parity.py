@@ -442,7 +442,7 @@ def test_leaf_wait_changes_no_bit(gpu, orc):
         with pytest.raises(capi.MirtError):
             gpu.set_option("leaf_wait", 0)
     finally:
-        gpu.set_option("leaf_wait", 4); gpu.set_option("walk_yield", -1)
+        gpu.set_option("leaf_wait", -1); gpu.set_option("walk_yield", -1)
 
 
 def test_depth_limits(gpu, orc):
