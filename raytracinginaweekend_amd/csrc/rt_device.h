@@ -397,8 +397,14 @@ __device__ __forceinline__ void to_leaf_space(const P &pr, uint32_t info, f3 &o,
 // t of the closest accepted intersection of one primitive, or false.  Sphere: Hitables.cpp:20-43
 // (centre 0, SimpleObject.cpp:136); rect: Hitables.cpp:95-100.  a_dd = dot(dir,dir) is passed in
 // because it does not depend on the primitive when no rotation is live.
+// by2a / div_ok (the near-first walks' sphere leaves): div_prepare(2 * dot(d, d)), made once per ray with r1 = NaN where 2a lies
+// outside div_by's denominator range, and the wave-uniform promise t_min >= 2^-19.  The root's quotient is then div_by's five
+// operations instead of the twelve of a full division, for the same bits: its first product |q0| <= 2^19 says that the
+// numerator is below 2^40 (and nothing is NaN); a wave with a lane beyond that takes the plain division; a numerator below
+// div_by's range gives |t| < 2^-19 < t_min by either route -- rejected, t unused.
 template <bool CHAIN = false, class P>
-__device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, float t_max, float &t_out, const OpRec *ops = nullptr)
+__device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, float t_max, float &t_out, const OpRec *ops = nullptr,
+                                       const DivBy *by2a = nullptr, bool div_ok = false)
 {
     uint32_t info = pr.info;
     to_leaf_space<CHAIN>(pr, info, o, d, ops);
@@ -418,10 +424,24 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
             // deferred roots do the same.
             const float sq = MIRT_SQRT(disc), two_a = 2.0f * a;
             const float n1 = -b - sq, n2 = -b + sq;
-            const float q1 = n1 * __builtin_amdgcn_rcpf(two_a);
+            const float q1 = n1 * (by2a ? by2a->r1 : __builtin_amdgcn_rcpf(two_a));   // (the refined reciprocal is as good an estimate)
             const float band = 0.00001f * __builtin_fabsf(t_min);                 // around t_min of either sign (the test hooks take any t_min)
             const bool first = q1 > t_min + band, second = q1 < t_min - band;
-            float t = (first ? n1 : n2) / two_a;
+            const float num = first ? n1 : n2;
+            float t;
+            if (by2a && div_ok) {
+                const float q0 = num * by2a->r1;
+                const unsigned long long beyond = __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(q0) <= 0x1p19f));
+                uint32_t slow = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)beyond | (uint32_t)(beyond >> 32)));
+                asm volatile("" : "+s"(slow));                          // a branch on a scalar, not both forms and a select
+                if (__builtin_expect(slow == 0u, 1)) {
+                    const float q1 = __builtin_fmaf(__builtin_fmaf(-two_a, q0, num), by2a->r1, q0);      // div_by, from its first product on
+                    t = __builtin_fmaf(__builtin_fmaf(-two_a, q1, num), by2a->r1, q1);
+                } else {
+                    asm volatile("; plain division for the whole wave");
+                    t = num / two_a;
+                }
+            } else t = num / two_a;
             in = (t <= t_max) & (t >= t_min);
             if (!(first | second)) {
                 t = n1 / two_a;

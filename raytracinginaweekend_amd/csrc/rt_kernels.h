@@ -25,6 +25,9 @@ namespace mirt {
 #ifndef MIRT_BLOCK
 #define MIRT_BLOCK 256
 #endif
+#ifndef MIRT_LEAF_DIVBY
+#define MIRT_LEAF_DIVBY 1   // sphere leaves of the near-first walks: the root's quotient through div_by (rt_device.h prim_t)
+#endif
 #ifndef MIRT_LEAF_WANT
 #define MIRT_LEAF_WANT 4u   // closest_bvh2: lanes waiting on a leaf that start an object-test pass (option leaf_wait)
 #endif
@@ -494,13 +497,24 @@ __device__ __forceinline__ bool leaf_prim_t(const Prims<PLDS> &P, uint32_t p, f3
 // The leaf test of a scene whose objects are all single unrotated spheres (SceneDev::sph4): one 16-byte access per leaf instead of
 // the record's first sector in two, and prim_t with the kind known at compile time (no dispatch, no rotation check) -- the same
 // sphere arithmetic on the same operands.
-__device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t)
+__device__ __forceinline__ bool sphere_leaf_t(const float4 *sph4, uint32_t p, f3 o, f3 d, float t_min, float t_max, float &t, const DivBy &by2a, bool div_ok)
 {
     const f32x4_t r = *(GlobalF4)((const __attribute__((address_space(1))) unsigned char *)sph4 + (p << 4));   // 32-bit byte offset (fewer than 2^26 objects, as nodes)
     PrimRec pr;
     pr.off[0] = r.x; pr.off[1] = r.y; pr.off[2] = r.z; pr.info = 0u /* MIRT_PRIM_SPHERE, no rotation */; pr.ga[2] = r.w;
-    return prim_t(pr, o, d, t_min, t_max, t);
+    return prim_t(pr, o, d, t_min, t_max, t, nullptr, &by2a, div_ok);
 }
+// A walk's per-ray division constants for its sphere leaves (prim_t: by2a, div_ok)
+struct LeafDiv {
+    DivBy by2a; bool ok;
+    __device__ __forceinline__ LeafDiv(f3 d, float t_min)
+    {
+        const float two_a = 2.0f * dot(d, d);
+        by2a = div_prepare(two_a);
+        if (!div_den_ok(two_a)) by2a.r1 = __builtin_nanf("");
+        ok = MIRT_LEAF_DIVBY && t_min >= 0x1p-19f;
+    }
+};
 
 // MIRT_NODE_SOA (measurement only, tools: profiles/r03_trace_ablation.txt): the near-first walk's nodes as sixteen planes of
 // one dword per node ("coalesced SoA node fetches", north_star kernel item 2) instead of one 64-byte record.  A wave's lanes
@@ -567,6 +581,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
     const float4 *const sph4 = sgpr_pin(sc.sph4);
     leaf_want = sgpr_pin(leaf_want);
     const f3 invd = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);              // AABB.cpp:9
+    const LeafDiv ld(d, t_min);
     for (;;) {
         if (cur >= 0) {
             Node2 n;                                                      // always from memory: staging the top levels in LDS measured neutral, and the
@@ -593,7 +608,7 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
             if (at_leaf) {
                 if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
                     float t;
-                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, t_max, t)) { t_max = t; best = ~cur; }
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, t_max, t, ld.by2a, ld.ok)) { t_max = t; best = ~cur; }
                 } else {
                     uint32_t first = (uint32_t)~cur, cnt = 1;
                     if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83
@@ -633,6 +648,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const uint32_t lds_n = LTOP ? sgpr_pin(sc.lds_nodes) : 0u;
     leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
     const unsigned long long entered = wave_mask(cur != MIRT_CHILD_NONE);
+    const LeafDiv ld(d, t_min);
     for (;;) {
         if (cur >= 0) {
             Node2 n;
@@ -661,7 +677,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
             if (at_leaf) {
                 if (sph4) {                                               // wave-uniform: every object is one unrotated sphere
                     float t;
-                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, w.t_max, t)) { w.t_max = t; w.best = ~cur; }
+                    if (sphere_leaf_t(sph4, (uint32_t)~cur, o, d, t_min, w.t_max, t, ld.by2a, ld.ok)) { w.t_max = t; w.best = ~cur; }
                 } else {
                     uint32_t first = (uint32_t)~cur, cnt = 1;
                     if (!single) { const u32x2_t ob = ((GlobalU2)objs)[~cur]; first = ob.x; cnt = ob.y; }      // Object::Hit, SimpleObject.cpp:73-83

@@ -553,6 +553,35 @@ def test_axis_parallel_rays(gpu, orc, world):
     assert differs.sum() <= 8 and np.array_equal(g["t"].view(np.uint32)[differs], o["t"].view(np.uint32)[differs]) and (g["t"][differs] < o1["t"][differs]).all()
 
 
+def test_sphere_leaf_quotients_at_every_scale(gpu, orc):
+    """The near-first walks take a sphere leaf's root through div_by when the wave's operands lie in its range (rt_device.h
+    prim_t: by2a; 2a in [2^-20, 2^20], first product below 2^19) and through the plain division otherwise, whole wave.  Rays
+    whose directions are scaled by 2^-40 .. 2^40 -- waves of one scale and waves that mix them -- and origins far outside the
+    scene hit what the oracle hits, bit for bit, at the render's t_min and at a t_min below div_by's promise."""
+    s, cam = scene.spheres_world(1.5)
+    s.nodes = None
+    capi.build_bvh(s)
+    gpu.upload_scene(s)
+    rng = np.random.default_rng(4242)
+    n = 32768
+    org = (rng.standard_normal((n, 3)) * 4.0).astype(np.float32)
+    org[:, 1] = np.abs(org[:, 1]) + 0.3
+    tgt = (rng.standard_normal((n, 3)) * 3.0).astype(np.float32); tgt[:, 1] = 0.3
+    d = tgt - org
+    scales = np.array([2.0 ** e for e in (-40, -24, -11, -9, -3, 0, 3, 9, 11, 24, 40)], dtype=np.float32)
+    k = np.empty(n, dtype=np.int64)
+    k[: n // 2] = np.repeat(np.arange(n // 2 // 64) % len(scales), 64)         # whole waves of one scale
+    k[n // 2:] = rng.integers(0, len(scales), n - n // 2)                      # mixed waves
+    d = (d * scales[k][:, None]).astype(np.float32)
+    far = rng.random(n) < 0.05                                                 # numerators beyond 2^40
+    org[far] = (org[far] * np.float32(2.0 ** 30)).astype(np.float32)
+    for t_min in (0.001, 1e-7):
+        o, _ = orc.world_hit_batch(s, org, d, t_min, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
+        assert (o["prim"] >= 0).sum() > n // 4
+        g = gpu.world_hit_batch(org, d, t_min, FLT_MAX, capi.FLAG_ACCEL_ORDERED)
+        H.assert_hits_equal(g, o, f"sphere leaves, directions at every scale, t_min={t_min}", scene=s)
+
+
 def test_facing_rect_pairs(gpu, orc):
     """closest_list tests the lowest and the highest plane of an orientation class as ONE rect when every ray of a wave starts
     between them (rt_kernels.h rect_pair).  A room with a pair in each of the three orientations, more rects between the pairs,
