@@ -210,8 +210,8 @@ int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);
 
 /* -- scene ---------------------------------------------------------------------------------- */
 /* Replaces the pointer graph TraceRay walks through World::GetObjectBVHTree()/GetLightSources()
- * (World.h:28,31).  Limits: a BVH of at most 60 levels and fewer than 2^26 nodes / objects (the walks address node and
- * leaf records by 32-bit byte offsets); MIRT_ERR_ARG beyond. */
+ * (World.h:28,31).  Limits: a BVH of at most 60 levels, fewer than 2^25 nodes and fewer than 2^26 objects (the walks address
+ * node and leaf records by signed 32-bit byte offsets); MIRT_ERR_ARG beyond. */
 int mirt_upload_scene(mirt_ctx *ctx, const mirt_scene *scene);
 /* Host-only, needs no GPU: the library's own BVH builder (binned SAH), the one mirt_upload_scene runs for a
  * scene without a tree.  The reference's counterpart is the SimpleObjectBVHNode constructor

@@ -229,7 +229,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     why = host::prepare_tree(*s, tree);
     if (!why.empty()) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: " + why);
     if (tree.depth > 60) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: BVH deeper than 60 levels");
-    if (tree.box.size() >= (1u << 26) || s->n_objects >= (1u << 26)) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: 2^26 BVH nodes / objects or more (the walks address them by 32-bit byte offsets)");
+    if (tree.box.size() >= (1u << 25) || s->n_objects >= (1u << 26)) return fail(c, MIRT_ERR_ARG, "mirt_upload_scene: 2^25 BVH nodes or 2^26 objects, or more (the walks address them by 32-bit byte offsets)");
     // From here on the context's buffers are rewritten in place (DevBuf::ensure frees before it allocates): until every
     // allocation and copy has succeeded the context has no scene, so a failed re-upload cannot leave render or batch
     // calls with pointers to freed buffers.
@@ -315,12 +315,15 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     for (size_t i = 0; i < nodes2.size(); ++i) {
         Node2 &n = nodes2[i]; memset(&n, 0, sizeof n);
         n.left = tree.left[i]; n.right = tree.right[i];
+        n.lleaf = (uint32_t)n.left >> 31; n.rleaf = (uint32_t)n.right >> 31;
         auto child_box = [&](int32_t ch) -> host::Box {
             if (ch == MIRT_CHILD_NONE) { host::Box e; for (int a = 0; a < 3; ++a) { e.mn[a] = 3.402823466e+38f; e.mx[a] = -3.402823466e+38f; } return e; }
             return ch < 0 ? tree.obox[~ch] : tree.box[ch];
         };
         host::Box l = child_box(n.left), r = child_box(n.right);
         for (int a = 0; a < 3; ++a) { n.lmn[a] = l.mn[a]; n.lmx[a] = l.mx[a]; n.rmn[a] = r.mn[a]; n.rmx[a] = r.mx[a]; }
+        if (n.left >= 0) n.left <<= 6;                 // children that are nodes as byte offsets (fetch_node2): no shift per step
+        if (n.right >= 0) n.right <<= 6;
     }
     std::vector<uint2> objs(s->n_objects);
     bool single = true;
@@ -419,6 +422,7 @@ extern "C" int mirt_upload_scene(mirt_ctx *c, const mirt_scene *s)
     c->lds_bytes = used + d.lds_nodes * d.node_bytes;
     c->lds_stack_bytes = d.stack_lds * MIRT_BLOCK * 4u;
     c->sc2.node_bytes = (uint32_t)sizeof(Node2);
+    if (c->sc2.root >= 0) c->sc2.root <<= 6;                        // the near-first walks name a node by its byte offset (Node2::left)
     // near-first walks read their nodes from memory, except the sliced walk of a large tree, which takes the top levels from LDS
     // (k_trace_bvh<4, ...>, rt_kernels.h bvh2_slice<.., LTOP>): option lds_top, -1 = 32 nodes for trees of 65536 nodes and more
     c->sc2.lds_nodes = std::min<uint32_t>(c->lds_top >= 0 ? (uint32_t)c->lds_top : (c->sc2.n_nodes >= 65536u ? 32u : 0u), c->sc2.n_nodes);

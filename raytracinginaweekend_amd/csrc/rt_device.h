@@ -288,10 +288,10 @@ struct PrimRec {            // 64 B; a sphere lives entirely in the first 32 B (
 // rot[0] = (as bits) index of its first OpRec; ops are stored outermost first.
 struct OpRec { uint32_t kind; float a, b, c; };   // 16 B: MIRT_OP_TRANSLATE: offset a,b,c; MIRT_OP_ROTATE_X/Y/Z: sin a, cos b
 struct Node2 {              // 64 B: both children's boxes in the parent, for near-first traversal
-    float   lmn[3]; int32_t left;
+    float   lmn[3]; int32_t left;      // a node: its BYTE OFFSET in the array (index << 6); an object: ~index; MIRT_CHILD_NONE
     float   lmx[3]; int32_t right;
-    float   rmn[3]; uint32_t pad0;
-    float   rmx[3]; uint32_t pad1;
+    float   rmn[3]; uint32_t lleaf;    // 1 when the left / right child is an object (or none): what slab_hit adds to t_max's bits,
+    float   rmx[3]; uint32_t rleaf;    // stored so that no lane has to shift it out of the child index at every step
 };
 struct NodeRec {            // 32 B: one aligned 32-byte sector per (per-lane, divergent) node fetch
     float   mn[3]; int32_t left;

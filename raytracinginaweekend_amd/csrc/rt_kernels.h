@@ -392,7 +392,7 @@ __device__ __forceinline__ int32_t closest_list(const SceneDev &sc, const LdsVie
 // LEAF: the child is an object, which the reference never box-tests (SimpleObjectBVHNode::Hit tests its own box, then
 // calls Object::Hit): its box may only cull what the primitives inside cannot hit, so a grazing interval
 // (t_max == t_min: a ray through a box edge or corner, where a primitive can lie) passes.
-__device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, int32_t child, float &t_near)
+__device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f3 o, f3 invd, float t_min, float t_max, uint32_t leaf, float &t_near)
 {
 #pragma unroll
     for (uint32_t a = 0; a < 3; ++a) {
@@ -402,12 +402,15 @@ __device__ __forceinline__ bool slab_hit(const float mn[3], const float mx[3], f
         const bool neg = id < 0.0f;
         const float tn = neg ? t1 : t0, tf = neg ? t0 : t1;
         t_min = __builtin_fmaxf(tn, t_min);
-        t_max = __builtin_fminf(tf, t_max);
+        // the caller's t_max enters through a bare v_min_f32: the builtin first canonicalises an operand it cannot trace to an
+        // arithmetic result (v_max_f32 x, x -- quieting a signalling NaN t_max never is), one instruction in every node step
+        if (a == 0) asm("v_min_f32 %0, %1, %2" : "=v"(t_max) : "v"(tf), "v"(t_max));
+        else t_max = __builtin_fminf(tf, t_max);
     }
     t_near = t_min;
-    // child < 0 (an object): "t_max < t_min -> miss", written as the node rule on the next float above t_max (t_max > 0
+    // leaf = 1 (the child is an object; Node2::lleaf / rleaf): "t_max < t_min -> miss", written as the node rule on the next float above t_max (t_max > 0
     // whenever the answer can be "hit"; +inf steps to NaN, which the negated compare passes)
-    const float t_top = __uint_as_float(__float_as_uint(t_max) + ((uint32_t)child >> 31));
+    const float t_top = __uint_as_float(__float_as_uint(t_max) + leaf);
     return !(t_top <= t_min);
 }
 
@@ -526,16 +529,16 @@ struct LeafDiv {
 __device__ __forceinline__ void fetch_node2(const Node2 *nodes2, uint32_t n_nodes, int32_t cur, f32x4_t &a, f32x4_t &b, f32x4_t &c, f32x4_t &e)
 {
 #if MIRT_NODE_SOA
-    const __attribute__((address_space(1))) float *pl = (const __attribute__((address_space(1))) float *)nodes2 + cur;
+    const __attribute__((address_space(1))) float *pl = (const __attribute__((address_space(1))) float *)nodes2 + (cur >> 6);
     const size_t n = n_nodes;
     a.x = pl[0]; a.y = pl[n]; a.z = pl[2 * n]; a.w = pl[3 * n];
     b.x = pl[4 * n]; b.y = pl[5 * n]; b.z = pl[6 * n]; b.w = pl[7 * n];
     c.x = pl[8 * n]; c.y = pl[9 * n]; c.z = pl[10 * n]; c.w = pl[11 * n];
     e.x = pl[12 * n]; e.y = pl[13 * n]; e.z = pl[14 * n]; e.w = pl[15 * n];
 #else
-    // byte offset in 32 bits (the upload refuses trees of 2^26 nodes and more): base in SGPRs + a 32-bit lane offset is one shift
-    // per step, where the signed 64-bit index arithmetic of `nodes2 + cur` is a 64-bit shift and a 64-bit add
-    const GlobalF4 g = (GlobalF4)((const __attribute__((address_space(1))) unsigned char *)nodes2 + ((uint32_t)cur << 6));
+    // `cur` IS the byte offset (Node2::left; the upload refuses trees of 2^25 nodes and more): base in SGPRs + a 32-bit lane
+    // offset costs nothing per step, where the signed 64-bit index arithmetic of `nodes2 + index` is a 64-bit shift and add
+    const GlobalF4 g = (GlobalF4)((const __attribute__((address_space(1))) unsigned char *)nodes2 + (uint32_t)cur);
     a = g[0]; b = g[1]; c = g[2]; e = g[3];
 #endif
 }
@@ -591,8 +594,8 @@ __device__ __forceinline__ int32_t closest_bvh2(const SceneDev &sc, const LdsVie
             n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
             n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
             float tl = 0.0f, tr = 0.0f;
-            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, n.left, tl);
-            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, n.right, tr);
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, t_max, __float_as_uint(c.w), tl);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, t_max, __float_as_uint(e.w), tr);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 stk.push(left_first ? n.right : n.left);
@@ -645,7 +648,7 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
     const uint2 *const objs = sgpr_pin(sc.objs);
     const uint32_t single = sgpr_pin(sc.single);
     const float4 *const sph4 = sgpr_pin(sc.sph4);
-    const uint32_t lds_n = LTOP ? sgpr_pin(sc.lds_nodes) : 0u;
+    const uint32_t lds_n = LTOP ? sgpr_pin(sc.lds_nodes << 6) : 0u;   // in bytes, like cur
     leaf_want = sgpr_pin(leaf_want); want = sgpr_pin(want);
     const unsigned long long entered = wave_mask(cur != MIRT_CHILD_NONE);
     const LeafDiv ld(d, t_min);
@@ -653,14 +656,14 @@ __device__ __forceinline__ void bvh2_slice(const SceneDev &sc, const LdsView &v,
         if (cur >= 0) {
             Node2 n;
             f32x4_t a, b, c, e;
-            if (LTOP && (uint32_t)cur < lds_n) { const LdsF4 l = (LdsF4)v.nodes + 4 * cur; a = l[0]; b = l[1]; c = l[2]; e = l[3]; }   // the top of the tree: LDS reads, not L1 accesses
+            if (LTOP && (uint32_t)cur < lds_n) { const LdsF4 l = (LdsF4)(v.nodes + (uint32_t)cur); a = l[0]; b = l[1]; c = l[2]; e = l[3]; }   // the top of the tree: LDS reads, not L1 accesses
             else fetch_node2(nodes2, n_nodes, cur, a, b, c, e);
             n.lmn[0] = a.x; n.lmn[1] = a.y; n.lmn[2] = a.z; n.left = __float_as_int(a.w);
             n.lmx[0] = b.x; n.lmx[1] = b.y; n.lmx[2] = b.z; n.right = __float_as_int(b.w);
             n.rmn[0] = c.x; n.rmn[1] = c.y; n.rmn[2] = c.z; n.rmx[0] = e.x; n.rmx[1] = e.y; n.rmx[2] = e.z;
             float tl = 0.0f, tr = 0.0f;
-            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, w.t_max, n.left, tl);
-            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, w.t_max, n.right, tr);
+            const bool hl = slab_hit(n.lmn, n.lmx, o, invd, t_min, w.t_max, __float_as_uint(c.w), tl);
+            const bool hr = (n.right != MIRT_CHILD_NONE) & slab_hit(n.rmn, n.rmx, o, invd, t_min, w.t_max, __float_as_uint(e.w), tr);
             if (hl && hr) {
                 const bool left_first = tl <= tr;
                 stk.push(left_first ? n.right : n.left);
