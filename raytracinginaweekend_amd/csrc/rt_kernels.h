@@ -1074,8 +1074,9 @@ struct TraceArgs {
 // 128 entries: topped up whenever fewer than 64 remain, so one pass always serves every idle lane (list walk:
 // the cheapest loop).  64 entries: drained completely before the refill, two passes when the idle lanes
 // outnumber what is left (BVH walks: iterations are long, LDS is what limits residency).
-template <int N>
-struct StashLds { float4 a[N], b[N]; };   // a = (ox, oy, oz, dx), b = (dy, dz, path id, sample of the batch): two 16-byte LDS accesses per ray
+template <int N, bool PIX = false>
+struct StashLds { float4 a[N], b[N]; uint32_t pix[PIX ? N : 1]; };   // a = (ox, oy, oz, dx), b = (dy, dz, path id, sample of the batch): two 16-byte LDS accesses per ray;
+                                                                      // pix (BVH kernels, whose path ids are tiled): the ray's pixel, which its generation computed anyway
 
 __device__ __forceinline__ void wave_lds_sync()
 {
@@ -1121,7 +1122,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     __shared__ CoopLdsT<SHARE> s_coop[MIRT_BLOCK / 64];
     constexpr bool BIG_STASH = ACCEL == 0;
     constexpr uint32_t STASH_N = BIG_STASH ? MIRT_LIST_STASH : 64u;
-    __shared__ StashLds<STASH_N> s_stash[MIRT_BLOCK / 64];
+    __shared__ StashLds<STASH_N, ACCEL != 0> s_stash[MIRT_BLOCK / 64];
     __shared__ uint32_t s_hist[65];
 
     if (a.own_chunks == 0u && (uint64_t)blockIdx.x * a.claim >= a.n_paths) return;   // more workgroups than claims (uniform)
@@ -1286,7 +1287,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const float4 qa = stash.a[e], qb = stash.b[e];
                         o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                         const uint32_t sl = __float_as_uint(qb.w);
-                        sample = a.spp0 + sl; pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
+                        sample = a.spp0 + sl;
+                        // the tiled pixel from the stash: tile_pixel's division by the run-time tiles_x is ~20 instructions in every pass
+                        if constexpr (ACCEL != 0) pixel = stash.pix[e]; else pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
                         thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                     }
                     cnt -= take; served += take;
@@ -1299,9 +1302,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                         const uint32_t id = w_next + lane;
                         const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
                         f3 go, gd;
-                        generate_ray(ka, tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width), ka.spp0 + sl, go, gd);
+                        const uint32_t px = tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width);
+                        generate_ray(ka, px, ka.spp0 + sl, go, gd);
                         stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
                         stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
+                        if constexpr (ACCEL != 0) stash.pix[lane] = px;
                     }
                     w_next += g; cnt = g; x_made += g;
                     wave_lds_sync();
