@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
     lds_stage(a.sc, lv);                                            // ends with a barrier
     // the wave's index is wave-uniform, and the compiler must be told: derived from threadIdx it counts as divergent, and with it
     // the whole of the wave's bookkeeping (claimed ids, stash count) -- vector registers and vector instructions for scalar work
-    const uint32_t lane = threadIdx.x & 63u, wave = ACCEL == 0 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     auto &stash = s_stash[wave];
 
     // wave-uniform bookkeeping
@@ -1277,39 +1277,45 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
             // camera rays (HomemadeRayTracer.cpp:114-131) into the now empty stash and serves the rest
             const unsigned long long idle = __ballot(!live);
             if (idle != 0ull && (cnt != 0u || !exhausted)) {
+                // without a loop: what the stash holds, then at most one round of 64 new rays (a claim that ends short of the idle
+                // lanes leaves the rest idle for one pass).  Written as a loop ("until every idle lane is served") the compiler took
+                // the wave's bookkeeping -- counts, claimed ids -- for divergent and kept it in vector registers
                 const uint32_t n_idle = (uint32_t)__popcll(idle);
                 const uint32_t rank = rank_in(idle);
-                uint32_t served = 0;
-                for (;;) {
-                    const uint32_t take = (n_idle - served < cnt) ? n_idle - served : cnt;
-                    if (!live && rank >= served && rank < served + take) {
-                        const uint32_t e = cnt - 1u - (rank - served);
+                auto take_from = [&](uint32_t first, uint32_t take) {
+                    if (!live && rank >= first && rank < first + take) {
+                        const uint32_t e = cnt - 1u - (rank - first);
                         const float4 qa = stash.a[e], qb = stash.b[e];
                         o = mk(qa.x, qa.y, qa.z); d = mk(qa.w, qb.x, qb.y); pid = __float_as_uint(qb.z);
                         const uint32_t sl = __float_as_uint(qb.w);
                         sample = a.spp0 + sl;
-                        // the tiled pixel from the stash: tile_pixel's division by the run-time tiles_x is ~20 instructions in every pass
                         if constexpr (ACCEL != 0) pixel = stash.pix[e]; else pixel = path_pixel(a.pix0 + (pid - sl * a.npix));
                         thr = mk(1.0f, 1.0f, 1.0f); depth = 0; live = true;
                     }
-                    cnt -= take; served += take;
-                    wave_lds_sync();                                // entries read above may be rewritten below
-                    if (served == n_idle || exhausted) break;
-                    if (w_next == w_end && !next_range()) { exhausted = true; break; }
-                    const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
-                    if (lane < g) {
-                        const TraceArgs &ka = late_args();
-                        const uint32_t id = w_next + lane;
-                        const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
-                        f3 go, gd;
-                        const uint32_t px = tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width);
-                        generate_ray(ka, px, ka.spp0 + sl, go, gd);
-                        stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
-                        stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
-                        if constexpr (ACCEL != 0) stash.pix[lane] = px;
+                };
+                const uint32_t take1 = n_idle < cnt ? n_idle : cnt;
+                if (take1 != 0u) { take_from(0u, take1); cnt -= take1; wave_lds_sync(); }
+                if (take1 != n_idle && !exhausted) {                  // the stash is empty now
+                    if (w_next == w_end && !next_range()) exhausted = true;
+                    else {
+                        const uint32_t g = (w_end - w_next < 64u) ? w_end - w_next : 64u;
+                        if (lane < g) {
+                            const TraceArgs &ka = late_args();
+                            const uint32_t id = w_next + lane;
+                            const uint32_t sl = fast_div(id, ka.by_npix), pl = id - sl * ka.npix;
+                            f3 go, gd;
+                            const uint32_t px = tile_pixel(ka.pix0 + pl, ka.by_tiles_x, ka.width);
+                            generate_ray(ka, px, ka.spp0 + sl, go, gd);
+                            stash.a[lane] = make_float4(go.x, go.y, go.z, gd.x);
+                            stash.b[lane] = make_float4(gd.y, gd.z, __uint_as_float(id), __uint_as_float(sl));
+                            if constexpr (ACCEL != 0) stash.pix[lane] = px;
+                        }
+                        w_next += g; cnt = g; x_made += g;
+                        wave_lds_sync();
+                        const uint32_t take2 = (n_idle - take1 < cnt) ? n_idle - take1 : cnt;
+                        take_from(take1, take2); cnt -= take2;
+                        wave_lds_sync();
                     }
-                    w_next += g; cnt = g; x_made += g;
-                    wave_lds_sync();
                 }
             }
         }
