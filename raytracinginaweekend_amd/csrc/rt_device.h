@@ -435,8 +435,8 @@ __device__ __forceinline__ bool prim_t(const P &pr, f3 o, f3 d, float t_min, flo
                 uint32_t slow = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)beyond | (uint32_t)(beyond >> 32)));
                 asm volatile("" : "+s"(slow));                          // a branch on a scalar, not both forms and a select
                 if (__builtin_expect(slow == 0u, 1)) {
-                    const float q1 = __builtin_fmaf(__builtin_fmaf(-two_a, q0, num), by2a->r1, q0);      // div_by, from its first product on
-                    t = __builtin_fmaf(__builtin_fmaf(-two_a, q1, num), by2a->r1, q1);
+                    const float qr = __builtin_fmaf(__builtin_fmaf(-two_a, q0, num), by2a->r1, q0);      // div_by, from its first product on
+                    t = __builtin_fmaf(__builtin_fmaf(-two_a, qr, num), by2a->r1, qr);
                 } else {
                     asm volatile("; plain division for the whole wave");
                     t = num / two_a;

@@ -1257,7 +1257,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 }
             }
             // ---- idle lanes take a fresh path from the top of the stash
-            const unsigned long long idle = wave_mask(!live);        // (the flag IS a lane mask: its ballot is an s_and with exec, where __ballot's int costs a select and a compare)
+            const unsigned long long idle = __ballot(!live);
             if (idle != 0ull && cnt != 0u) {
                 const uint32_t rank = rank_in(idle);
                 if (!live && rank < cnt) {
@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
         } else {
             // ---- idle lanes take what the stash holds; if lanes are still idle, the whole wave makes 64 new
             // camera rays (HomemadeRayTracer.cpp:114-131) into the now empty stash and serves the rest
-            const unsigned long long idle = wave_mask(!live);        // (the flag IS a lane mask: its ballot is an s_and with exec, where __ballot's int costs a select and a compare)
+            const unsigned long long idle = __ballot(!live);
             if (idle != 0ull && (cnt != 0u || !exhausted)) {
                 // without a loop: what the stash holds, then at most one round of 64 new rays (a claim that ends short of the idle
                 // lanes leaves the rest idle for one pass).  Written as a loop ("until every idle lane is served") the compiler took
@@ -1319,7 +1319,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs &a)
                 }
             }
         }
-        const unsigned long long live_now = wave_mask(live);
+        const unsigned long long live_now = __ballot(live);
         if (MIRT_TEXP & 16) ++x_iters;
         if (live_now == 0ull) {                                     // pool exhausted, stash empty, every path ended
             if constexpr (DEFER) { if (q_cnt != 0u) { service(q_cnt < 64u ? q_cnt : 64u); continue; } if (r_cnt != 0u) continue; }
