@@ -203,7 +203,7 @@ int         mirt_runtime_version(int *hip_runtime, int *hip_driver);
  *                   rows (compact patches of camera rays); 0: rows.  No effect on the image.
  *  "lds_budget", "stack_lds", "lds_mats", "lds_prims"  LDS plan of the next mirt_upload_scene: bytes per workgroup
  *                   up to which the top of the BVH is staged (default 4096), traversal-stack levels kept in LDS
- *                   (default 4, the rest spills to HBM), largest material table staged (default 1024 bytes),
+ *                   (default 5, the rest spills to HBM), largest material table staged (default 1024 bytes),
  *                   largest primitive table staged (default 4096 bytes; such scenes are walked as a list under
  *                   MIRT_FLAG_ACCEL_AUTO when they have at most 32 primitives) */
 int         mirt_set_option(mirt_ctx *ctx, const char *name, int64_t value);

@@ -87,7 +87,8 @@ struct mirt_ctx {
                                             // 0: off, -1 (default): 56 for batches of 2 Mi paths or more
     uint32_t tile_paths = 1;                // persistent engine, BVH walks: path ids over 8x8 pixel tiles (option tile_paths)
     uint32_t lds_mats = 1024u;              // the material table is staged in LDS if it is no larger than this; likewise
-    uint32_t stack_lds = 4;                // traversal-stack levels kept in LDS (1 KiB each; 4 measured best with the wave-synchronous walk, 1-8 within 3 %); likewise
+    uint32_t stack_lds = 5;                // traversal-stack levels kept in LDS (1 KiB each; round 3's last sweep, 2/3/4/5/6/8 levels: 485 spheres 12.44/12.21/12.16/12.14/12.10/12.58 ms,
+                                           // ~1 M spheres 13.32/13.04/12.95/12.78/13.10/16.3 ms: profiles/r03_walk_thresholds.txt); likewise
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int n_cu = 256;
